@@ -1,0 +1,151 @@
+/*
+ * rt_amd.h -- C ABI of the MI355X-native per-pixel ray-tracing hot path.
+ *
+ * Drop-in boundary for the L1<->L0 seam of camms205/ray-tracing: what src/node.rs and
+ * src/pipeline.rs hand to wgpu today.  The reference has no FFI of its own (SURVEY.md
+ * section 8b); each entry point cites the reference interface it replaces.  Plain
+ * pointers and sizes only; no C++/torch types; every call returns an int status; nothing
+ * throws or aborts across this boundary.  INTEGRATION.md shows the Rust `-sys` binding.
+ *
+ * Threading: a context is not re-entrant; callers serialise per context (the reference
+ * calls RayTracingPassNode::run from one render thread, src/node.rs:29).  One context per
+ * GPU.  Host pointers are borrowed for the duration of the call only.
+ */
+#ifndef RT_AMD_H
+#define RT_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- status codes ---------------------------------------------------------------- */
+#define RT_OK            0
+#define RT_NOT_READY     1   /* no scene or no view yet: the frame is skipped, mirroring the
+                                silent `return Ok(())` of src/node.rs:52-56. Not an error. */
+#define RT_ERR_ARG      -1
+#define RT_ERR_HIP      -2   /* a HIP runtime call failed; rt_last_error() has the text */
+#define RT_ERR_NO_GPU   -3   /* no usable gfx950 device: the library has NO CPU fallback */
+#define RT_ERR_SCENE    -4   /* scene arrays inconsistent (index out of range, ...) */
+#define RT_ERR_OOM      -5
+
+/* ---- scene data contract: byte-identical to the RayTracingInfo bindings ---------- */
+/* T1  Triangle   src/ray_tracing.rs:51-54, ray_tracing.wgsl:19-23.  12 B. */
+typedef struct { uint32_t indices[3]; } rt_triangle;
+/* T2  MeshInfo   src/ray_tracing.rs:56-63, ray_tracing.wgsl:24-30.  48 B (std430). */
+typedef struct {
+    uint32_t first_tri, tri_count, material, _pad0;
+    float aabb_min[3]; float _pad1;
+    float aabb_max[3]; float _pad2;
+} rt_mesh_info;
+/* T3  Vertex     src/ray_tracing.rs:92-93 ([Vec3;2]), ray_tracing.wgsl:14-17.  32 B. */
+typedef struct { float pos[3]; float _pad0; float norm[3]; float _pad1; } rt_vertex;
+/* T4  SimpleMaterial  src/ray_tracing.rs:65-68, ray_tracing.wgsl:32-34.  16 B. */
+typedef struct { float color[4]; } rt_material;
+
+typedef struct rt_ctx rt_ctx;
+
+/* ---- lifecycle: replaces RayTracingPipeline::from_world (src/pipeline.rs:25-72) ----- */
+int rt_create(int device_ordinal, rt_ctx **out);
+int rt_destroy(rt_ctx *ctx);
+/* Run all work of this context on an existing HIP stream (hipStream_t passed as void*);
+ * NULL restores the context's own stream. */
+int rt_set_stream(rt_ctx *ctx, void *hip_stream);
+
+/* ---- scene upload: replaces as_bind_group's per-frame buffer creation ---------------
+ * (src/node.rs:42-50; bindings 1-4 of RayTracingInfo, src/ray_tracing.rs:84-96).
+ * Host arrays in the exact T1-T4 layouts.  The library copies them, re-lays them out and
+ * builds its BVH.  Call when the scene changes, not per frame. */
+int rt_upload_scene(rt_ctx *ctx,
+                    const rt_triangle *triangles, size_t n_triangles,
+                    const rt_mesh_info *meshes, size_t n_meshes,
+                    const rt_vertex *vertices, size_t n_vertices,
+                    const rt_material *materials, size_t n_materials);
+
+/* ---- view: replaces bind group 0 (View uniform, dynamic offset) and
+ * set_camera_viewport (src/node.rs:58-62,71-76; ray_tracing.wgsl:5,176-177).
+ * world_from_clip: column-major f32 4x4.  viewport = {x,y,w,h} or NULL for the full target. */
+int rt_set_view(rt_ctx *ctx, const float world_from_clip[16], const float world_position[3],
+                uint32_t width, uint32_t height, const uint32_t viewport[4]);
+
+/* ---- render: replaces render_pass.draw(0..3, 0..1) (src/node.rs:77) ------------------- */
+#define RT_FLAG_SHADOW        0x0001u  /* trace the build-defined shadow ray toward +Y */
+#define RT_FLAG_NO_MESH_CULL  0x0002u  /* extension: ignore the per-mesh AABB cull (wgsl:155) */
+#define RT_FLAG_BRUTE_FORCE   0x0004u  /* reference-shaped two-level loop (wgsl:150-170), no BVH */
+#define RT_FLAG_COUNTERS      0x0008u  /* instrumented kernels: count node visits / tests */
+#define RT_FLAG_PATH_TRACE    0x0010u  /* progressive path tracing (wgsl:180-202 loop shape) */
+#define RT_FLAG_ACCUMULATE    0x0020u  /* keep the accumulation buffer from earlier frames */
+#define RT_FLAG_TIME_KERNELS  0x0040u  /* bracket kernels with HIP events (rt_get_counters) */
+
+typedef struct {
+    uint32_t struct_size;    /* = sizeof(rt_render_params) */
+    uint32_t flags;
+    uint32_t frame_count;    /* the `count` uniform (src/ray_tracing.rs:86-87); informational */
+    uint32_t spp;            /* path tracing: samples this call */
+    uint32_t sample_first;   /* global index of this call's first sample (sample slicing) */
+    uint32_t max_segments;   /* path tracing: ray segments per path (reference shape: 4) */
+    uint32_t seed;
+    uint32_t stream_id;      /* RNG stream (= rank for sample slicing) */
+    uint32_t shard_rank;     /* screen-tile sharding: this context renders the tiles whose */
+    uint32_t shard_count;    /*   index % shard_count == shard_rank; 0 or 1 = all tiles  */
+    uint32_t tile_size;      /* shard tile edge in pixels (0 = 64) */
+    uint32_t _reserved;
+} rt_render_params;
+
+/* Asynchronous on the context's stream.  params may be NULL (one primary ray per pixel,
+ * the live path of ray_tracing.wgsl:203-211). */
+int rt_render(rt_ctx *ctx, const rt_render_params *params);
+int rt_synchronize(rt_ctx *ctx);
+
+/* ---- results: replace the colour-attachment write (src/node.rs:63-69) -----------------
+ * Caller-allocated host buffers; each call synchronises the stream first.
+ * radiance: W*H*4 f32 linear unclamped RGBA (path tracing: accumulated sum / samples).
+ * prim ids: W*H u32, global triangle index of the primary hit, 0xFFFFFFFF on a miss.
+ * hit t:    W*H f32, 0 on a miss.
+ * bgra8:    W*H*4 u8, clamp + sRGB encode as the Bgra8UnormSrgb target (src/pipeline.rs:56-60). */
+int rt_read_radiance(rt_ctx *ctx, float *rgba, size_t n_floats);
+int rt_read_prim_ids(rt_ctx *ctx, uint32_t *prim, size_t n);
+int rt_read_hit_t(rt_ctx *ctx, float *t, size_t n);
+int rt_read_bgra8_srgb(rt_ctx *ctx, uint8_t *bgra, size_t n_bytes);
+int rt_read_accumulation(rt_ctx *ctx, float *accum, size_t n_floats);
+
+/* Device-side access for callers that keep results on the GPU (multi-GPU combine with RCCL):
+ * pointers into the context's own buffers, valid until the next rt_set_view with a different
+ * size or rt_destroy. */
+int rt_device_buffers(rt_ctx *ctx, void **d_radiance, void **d_prim, void **d_accum);
+/* radiance = accum / total_samples on the device (after an external reduce). */
+int rt_resolve_accumulation(rt_ctx *ctx, uint32_t total_samples);
+
+/* ---- counters, introspection, errors ------------------------------------------------- */
+typedef struct {
+    uint64_t rays_primary, rays_shadow, rays_bounce;
+    uint64_t node_visits;        /* BVH nodes fetched (RT_FLAG_COUNTERS only) */
+    uint64_t tri_tests;          /* ray/triangle tests (RT_FLAG_COUNTERS only) */
+    uint64_t mesh_aabb_tests;    /* per-mesh culls evaluated (RT_FLAG_COUNTERS only) */
+    double   kernel_ms;          /* device time of the last rt_render's kernels (TIME_KERNELS) */
+    uint32_t kernel_launches;
+    uint32_t _pad;
+} rt_counters;
+int rt_get_counters(rt_ctx *ctx, rt_counters *out);
+
+typedef struct {
+    uint64_t n_nodes, n_triangles, n_meshes, n_vertices;
+    uint32_t node_bytes, tri_bytes;  /* bytes per BVH node / per leaf triangle record */
+    uint32_t max_depth, max_leaf;
+    double   build_ms;
+    double   sah_cost;
+} rt_bvh_info;
+int rt_get_bvh_info(rt_ctx *ctx, rt_bvh_info *out);
+/* Copy the flattened BVH out (host buffers sized from rt_get_bvh_info). */
+int rt_read_bvh(rt_ctx *ctx, void *nodes, size_t node_bytes_total, void *tris, size_t tri_bytes_total);
+
+const char *rt_last_error(rt_ctx *ctx);   /* ctx may be NULL: last error of rt_create */
+const char *rt_status_string(int status);
+const char *rt_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RT_AMD_H */

@@ -1,0 +1,285 @@
+// bvh_build.cpp -- binned-SAH BVH2 builder over the reference's (mesh, triangle) loop items.
+// Build-side design (reference src/bvh.rs:1 is empty).  Host code, no GPU calls.
+#include "bvh_build.h"
+
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <cmath>
+#include <cstring>
+#include <limits>
+#include <thread>
+
+namespace {
+
+struct Prim {
+    float lo[3], hi[3], c[3];
+    uint32_t seq, tri, mesh;
+};
+
+struct TmpNode {
+    float lo[3], hi[3];
+    int32_t left, right;       // inner: indices of TmpNodes; leaf: -1
+    uint32_t first, count;     // leaf: run in the prim array
+};
+
+constexpr int kBins = 16;
+constexpr float kCostNode = 1.0f, kCostTri = 1.0f;
+constexpr size_t kSpawnMin = 1u << 15;
+
+inline float half_area(const float *lo, const float *hi) {
+    float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+    return dx * dy + dy * dz + dz * dx;
+}
+inline void box_reset(float *lo, float *hi) {
+    for (int k = 0; k < 3; ++k) { lo[k] = std::numeric_limits<float>::infinity(); hi[k] = -lo[k]; }
+}
+inline void box_grow(float *lo, float *hi, const float *blo, const float *bhi) {
+    for (int k = 0; k < 3; ++k) { lo[k] = std::min(lo[k], blo[k]); hi[k] = std::max(hi[k], bhi[k]); }
+}
+
+struct Builder {
+    std::vector<Prim> prims;
+    std::vector<TmpNode> nodes;
+    std::atomic<uint32_t> next_node{0};
+    std::atomic<int> free_threads{0};
+    std::atomic<uint32_t> max_depth{0};
+
+    uint32_t alloc() { return next_node.fetch_add(1); }
+
+    void note_depth(uint32_t d) {
+        uint32_t cur = max_depth.load();
+        while (d > cur && !max_depth.compare_exchange_weak(cur, d)) {}
+    }
+
+    // Builds the subtree for prims[b,e) into nodes[ni]; depth = depth of this node (root 0).
+    void build(uint32_t ni, size_t b, size_t e, uint32_t depth) {
+        TmpNode &N = nodes[ni];
+        box_reset(N.lo, N.hi);
+        float clo[3], chi[3];
+        box_reset(clo, chi);
+        for (size_t i = b; i < e; ++i) {
+            box_grow(N.lo, N.hi, prims[i].lo, prims[i].hi);
+            box_grow(clo, chi, prims[i].c, prims[i].c);
+        }
+        size_t n = e - b;
+        note_depth(depth);
+        auto make_leaf = [&]() { N.left = N.right = -1; N.first = (uint32_t)b; N.count = (uint32_t)n; };
+        if (n <= 1) { make_leaf(); return; }
+
+        // depth guard: the inner nodes below this one may use at most `room` more levels
+        uint32_t room = RT_MAX_DEPTH - 1 - depth;   // levels available for children inner nodes
+        size_t leaves_needed = (n + RT_MAX_LEAF - 1) / RT_MAX_LEAF;
+        uint32_t need = 0;
+        while (((size_t)1 << need) < leaves_needed) ++need;
+        bool force_median = need + 1 >= room;           // a balanced split still fits; SAH might not
+
+        int best_axis = -1, best_bin = -1;
+        float best_cost = std::numeric_limits<float>::infinity();
+        float parent_area = half_area(N.lo, N.hi);
+        if (!force_median) {
+            for (int ax = 0; ax < 3; ++ax) {
+                float ext = chi[ax] - clo[ax];
+                if (!(ext > 0.0f)) continue;
+                float scale = (float)kBins / ext;
+                uint32_t cnt[kBins] = {0};
+                float blo[kBins][3], bhi[kBins][3];
+                for (int k = 0; k < kBins; ++k) box_reset(blo[k], bhi[k]);
+                for (size_t i = b; i < e; ++i) {
+                    int k = (int)((prims[i].c[ax] - clo[ax]) * scale);
+                    k = k < 0 ? 0 : (k >= kBins ? kBins - 1 : k);
+                    cnt[k]++;
+                    box_grow(blo[k], bhi[k], prims[i].lo, prims[i].hi);
+                }
+                float ra[kBins]; uint32_t rc[kBins];
+                float lo[3], hi[3];
+                box_reset(lo, hi);
+                uint32_t c = 0;
+                for (int k = kBins - 1; k > 0; --k) {
+                    if (cnt[k]) box_grow(lo, hi, blo[k], bhi[k]);
+                    c += cnt[k];
+                    rc[k] = c; ra[k] = c ? half_area(lo, hi) : 0.0f;
+                }
+                box_reset(lo, hi);
+                c = 0;
+                for (int k = 0; k < kBins - 1; ++k) {
+                    if (cnt[k]) box_grow(lo, hi, blo[k], bhi[k]);
+                    c += cnt[k];
+                    if (c == 0 || rc[k + 1] == 0) continue;
+                    float cost = half_area(lo, hi) * (float)c + ra[k + 1] * (float)rc[k + 1];
+                    if (cost < best_cost) { best_cost = cost; best_axis = ax; best_bin = k; }
+                }
+            }
+        }
+        size_t mid = b;
+        if (best_axis >= 0) {
+            float split_cost = kCostNode + kCostTri * best_cost / (parent_area > 0.0f ? parent_area : 1.0f);
+            float leaf_cost = kCostTri * (float)n;
+            if (n <= RT_MAX_LEAF && leaf_cost <= split_cost) { make_leaf(); return; }
+            float ext = chi[best_axis] - clo[best_axis];
+            float scale = (float)kBins / ext;
+            float c0 = clo[best_axis];
+            int ax = best_axis, bin = best_bin;
+            Prim *p = std::partition(prims.data() + b, prims.data() + e, [=](const Prim &P) {
+                int k = (int)((P.c[ax] - c0) * scale);
+                k = k < 0 ? 0 : (k >= kBins ? kBins - 1 : k);
+                return k <= bin;
+            });
+            mid = (size_t)(p - prims.data());
+        }
+        if (mid == b || mid == e) {
+            // no usable SAH split (coincident centroids, or the depth guard): object median
+            if (n <= RT_MAX_LEAF) { make_leaf(); return; }
+            int ax = 0;
+            float ex = chi[0] - clo[0];
+            for (int k = 1; k < 3; ++k) if (chi[k] - clo[k] > ex) { ex = chi[k] - clo[k]; ax = k; }
+            mid = b + n / 2;
+            std::nth_element(prims.begin() + b, prims.begin() + mid, prims.begin() + e,
+                             [ax](const Prim &A, const Prim &B) {
+                                 return A.c[ax] < B.c[ax] || (A.c[ax] == B.c[ax] && A.seq < B.seq);
+                             });
+        }
+        uint32_t l = alloc(), r = alloc();
+        N.left = (int32_t)l; N.right = (int32_t)r; N.first = 0; N.count = 0;
+        size_t nl = mid - b;
+        if (std::min(nl, n - nl) >= kSpawnMin && free_threads.fetch_sub(1) > 0) {
+            std::thread t([this, l, b, mid, depth]() { build(l, b, mid, depth + 1); });
+            build(r, mid, e, depth + 1);
+            t.join();
+            free_threads.fetch_add(1);
+        } else {
+            if (std::min(nl, n - nl) >= kSpawnMin) free_threads.fetch_add(1); // undo failed grab
+            build(l, b, mid, depth + 1);
+            build(r, mid, e, depth + 1);
+        }
+    }
+};
+
+inline int32_t leaf_code(uint32_t first, uint32_t count) { return ~(int32_t)((first << 3) | (count - 1)); }
+
+}  // namespace
+
+void rt_bvh_build(const rt_triangle *tris, size_t n_tris, const rt_mesh_info *meshes, size_t n_meshes,
+                  const rt_vertex *verts, size_t n_verts, int n_threads, RtBvhBuildResult *out) {
+    (void)n_tris; (void)n_verts;
+    auto t0 = std::chrono::steady_clock::now();
+    out->nodes.clear(); out->recs.clear();
+    out->max_depth = 0; out->max_leaf = 0; out->sah_cost = 0.0; out->dropped = 0;
+
+    Builder B;
+    size_t total = 0;
+    for (size_t m = 0; m < n_meshes; ++m) total += meshes[m].tri_count;
+    B.prims.reserve(total);
+    uint32_t seq = 0;
+    for (size_t m = 0; m < n_meshes; ++m) {
+        for (uint32_t j = meshes[m].first_tri; j < meshes[m].first_tri + meshes[m].tri_count; ++j, ++seq) {
+            const float *a = verts[tris[j].indices[0]].pos;
+            const float *b = verts[tris[j].indices[1]].pos;
+            const float *c = verts[tris[j].indices[2]].pos;
+            Prim P;
+            bool finite = true;
+            float amax = 0.0f;
+            for (int k = 0; k < 3; ++k) {
+                finite = finite && std::isfinite(a[k]) && std::isfinite(b[k]) && std::isfinite(c[k]);
+                P.lo[k] = std::min(a[k], std::min(b[k], c[k]));
+                P.hi[k] = std::max(a[k], std::max(b[k], c[k]));
+                amax = std::max(amax, std::max(std::fabs(P.lo[k]), std::fabs(P.hi[k])));
+            }
+            // A triangle with a NaN/inf vertex can never pass ray_triangle's comparisons in a
+            // way a box could bound; it is left out of the tree.
+            if (!finite) { out->dropped++; continue; }
+            // pad so that rounding in the slab test can never cull a triangle the exact f32
+            // ray_triangle arithmetic accepts (DESIGN.md "Conservative culling")
+            float pad = 1e-5f * amax + 1e-30f;
+            for (int k = 0; k < 3; ++k) {
+                P.lo[k] -= pad; P.hi[k] += pad;
+                P.c[k] = 0.5f * P.lo[k] + 0.5f * P.hi[k];
+            }
+            P.seq = seq; P.tri = j; P.mesh = (uint32_t)m;
+            B.prims.push_back(P);
+        }
+    }
+    size_t n = B.prims.size();
+    if (n == 0) { out->build_ms = 0.0; return; }
+
+    if (n_threads <= 0) {
+        n_threads = (int)std::thread::hardware_concurrency();
+        if (n_threads > 16) n_threads = 16;
+        if (n_threads < 1) n_threads = 1;
+    }
+    B.free_threads = n_threads - 1;
+    B.nodes.resize(2 * n + 1);
+    uint32_t root = B.alloc();
+    B.build(root, 0, n, 0);
+
+    // leaf records in prim order
+    out->recs.resize(n);
+    for (size_t i = 0; i < n; ++i) {
+        const Prim &P = B.prims[i];
+        const float *a = verts[tris[P.tri].indices[0]].pos;
+        const float *b = verts[tris[P.tri].indices[1]].pos;
+        const float *c = verts[tris[P.tri].indices[2]].pos;
+        RtTriRecord &R = out->recs[i];
+        R.a[0] = a[0]; R.a[1] = a[1]; R.a[2] = a[2];
+        // edge_ab = b.pos - a.pos, edge_ac = c.pos - a.pos: plain f32 subtractions, the same
+        // values ray_tracing.wgsl:122-123 computes per test
+        R.abx = b[0] - a[0]; R.aby = b[1] - a[1]; R.abz = b[2] - a[2];
+        R.acx = c[0] - a[0]; R.acy = c[1] - a[1]; R.acz = c[2] - a[2];
+        R.tri = P.tri; R.mesh = P.mesh; R.seq = P.seq;
+    }
+
+    // flatten to the 64-B two-child layout, depth-first so a subtree is contiguous
+    const float qnan = std::numeric_limits<float>::quiet_NaN();
+    const TmpNode &R = B.nodes[root];
+    double root_area = half_area(R.lo, R.hi);
+    if (!(root_area > 0.0)) root_area = 1.0;
+    double sah = 0.0;
+    uint32_t max_leaf = 0;
+    if (R.left < 0) {
+        RtBvhNode node;
+        std::memset(&node, 0, sizeof node);
+        for (int k = 0; k < 3; ++k) { node.lo0[k] = R.lo[k]; node.hi0[k] = R.hi[k]; node.lo1[k] = qnan; node.hi1[k] = qnan; }
+        node.child0 = leaf_code(R.first, R.count);
+        node.child1 = RT_CHILD_NONE;
+        out->nodes.push_back(node);
+        max_leaf = R.count;
+        sah = kCostNode + kCostTri * R.count;
+    } else {
+        out->nodes.reserve(B.next_node.load() / 2 + 1);
+        struct Item { uint32_t tmp; uint32_t out; };
+        std::vector<Item> stack;
+        out->nodes.emplace_back();
+        stack.push_back({root, 0});
+        while (!stack.empty()) {
+            Item it = stack.back(); stack.pop_back();
+            const TmpNode &T = B.nodes[it.tmp];
+            sah += kCostNode * half_area(T.lo, T.hi) / root_area;
+            RtBvhNode node;
+            std::memset(&node, 0, sizeof node);
+            const TmpNode *ch[2] = {&B.nodes[T.left], &B.nodes[T.right]};
+            int32_t code[2];
+            for (int c = 0; c < 2; ++c) {
+                if (ch[c]->left < 0) {
+                    code[c] = leaf_code(ch[c]->first, ch[c]->count);
+                    max_leaf = std::max(max_leaf, ch[c]->count);
+                    sah += kCostTri * ch[c]->count * half_area(ch[c]->lo, ch[c]->hi) / root_area;
+                } else {
+                    uint32_t idx = (uint32_t)out->nodes.size();
+                    out->nodes.emplace_back();
+                    code[c] = (int32_t)idx;
+                    stack.push_back({(uint32_t)(c == 0 ? T.left : T.right), idx});
+                }
+            }
+            for (int k = 0; k < 3; ++k) {
+                node.lo0[k] = ch[0]->lo[k]; node.hi0[k] = ch[0]->hi[k];
+                node.lo1[k] = ch[1]->lo[k]; node.hi1[k] = ch[1]->hi[k];
+            }
+            node.child0 = code[0]; node.child1 = code[1];
+            out->nodes[it.out] = node;
+        }
+    }
+    out->max_depth = B.max_depth.load();
+    out->max_leaf = max_leaf;
+    out->sah_cost = sah;
+    out->build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+}

@@ -1,0 +1,20 @@
+// bvh_build.h -- host BVH builder (binned SAH, multithreaded).  Build-side design: the
+// reference's src/bvh.rs:1 is empty, its only acceleration is one AABB per mesh
+// (src/ray_tracing.rs:148-156).
+#pragma once
+#include <vector>
+#include "rt_layout.h"
+
+struct RtBvhBuildResult {
+    std::vector<RtBvhNode> nodes;     // nodes[0] is the root when non-empty
+    std::vector<RtTriRecord> recs;    // leaf order
+    uint32_t max_depth = 0, max_leaf = 0;
+    double sah_cost = 0.0, build_ms = 0.0;
+    uint64_t dropped = 0;             // records dropped for non-finite vertices
+};
+
+// Flattens the (mesh, triangle) loop of ray_tracing.wgsl:153,158 into records and builds the
+// tree.  Inputs must already be validated (indices in range).  n_threads <= 0: hardware
+// concurrency capped at 16.
+void rt_bvh_build(const rt_triangle *tris, size_t n_tris, const rt_mesh_info *meshes, size_t n_meshes,
+                  const rt_vertex *verts, size_t n_verts, int n_threads, RtBvhBuildResult *out);

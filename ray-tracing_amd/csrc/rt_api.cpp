@@ -1,0 +1,512 @@
+// rt_api.cpp -- the C ABI of include/rt_amd.h: context, device memory, streams, launches.
+// Replaces what src/pipeline.rs (init) and src/node.rs (per-frame launch) do through wgpu.
+// There is NO CPU fallback: without a gfx950 device rt_create fails with RT_ERR_NO_GPU.
+#include <hip/hip_runtime_api.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/rt_amd.h"
+#include "bvh_build.h"
+#include "rt_kernels.h"
+#include "rt_layout.h"
+
+namespace {
+thread_local std::string g_create_error;
+
+struct QueueMem {
+    float *f = nullptr;       // 9 float planes
+    uint32_t *u = nullptr;    // 2 u32 planes
+};
+}  // namespace
+
+struct rt_ctx {
+    int device = 0;
+    hipStream_t own_stream = nullptr, stream = nullptr;
+    std::string err;
+
+    // scene
+    bool has_scene = false;
+    RtSceneDev S{};
+    void *d_nodes = nullptr, *d_recs = nullptr, *d_tris = nullptr, *d_meshes = nullptr, *d_verts = nullptr,
+         *d_mats = nullptr;
+    rt_bvh_info info{};
+
+    // view + framebuffers
+    bool has_view = false;
+    RtViewDev V{};
+    size_t n_px = 0;
+    float *d_rgba = nullptr, *d_accum = nullptr, *d_t = nullptr;
+    uint32_t *d_prim = nullptr;
+    uint8_t *d_bgra = nullptr;
+    uint64_t coverage_sig = 0;       // what the buffers were last cleared for
+    uint32_t accum_samples = 0;
+    bool accum_dirty = false;        // camera moved: the next path-traced frame restarts accumulation
+
+    // path queues (2, ping-pong)
+    QueueMem q[2];
+    size_t q_capacity = 0;
+
+    // counters
+    unsigned long long *d_cnt = nullptr;
+    unsigned long long *h_cnt = nullptr;   // pinned
+    rt_counters counters{};
+    uint64_t primary_total = 0;
+
+    // kernel timing
+    std::vector<hipEvent_t> ev;            // pairs: start, stop
+    size_t ev_used = 0;
+};
+
+namespace {
+
+int fail(rt_ctx *c, int code, const char *what, hipError_t e = hipSuccess) {
+    char buf[512];
+    if (e != hipSuccess) snprintf(buf, sizeof buf, "%s: %s", what, hipGetErrorString(e));
+    else snprintf(buf, sizeof buf, "%s", what);
+    if (c) c->err = buf; else g_create_error = buf;
+    return code;
+}
+
+#define HIPCHK(c, call)                                                        \
+    do {                                                                       \
+        hipError_t e_ = (call);                                                \
+        if (e_ != hipSuccess) return fail((c), e_ == hipErrorOutOfMemory ? RT_ERR_OOM : RT_ERR_HIP, #call, e_); \
+    } while (0)
+
+void free_dev(void *&p) { if (p) { (void)hipFree(p); p = nullptr; } }
+
+void free_scene(rt_ctx *c) {
+    free_dev(c->d_nodes); free_dev(c->d_recs); free_dev(c->d_tris);
+    free_dev(c->d_meshes); free_dev(c->d_verts); free_dev(c->d_mats);
+    c->has_scene = false;
+    std::memset(&c->S, 0, sizeof c->S);
+}
+
+void free_frame(rt_ctx *c) {
+    void *p;
+    p = c->d_rgba; free_dev(p); c->d_rgba = nullptr;
+    p = c->d_accum; free_dev(p); c->d_accum = nullptr;
+    p = c->d_t; free_dev(p); c->d_t = nullptr;
+    p = c->d_prim; free_dev(p); c->d_prim = nullptr;
+    p = c->d_bgra; free_dev(p); c->d_bgra = nullptr;
+    for (int i = 0; i < 2; ++i) {
+        p = c->q[i].f; free_dev(p); c->q[i].f = nullptr;
+        p = c->q[i].u; free_dev(p); c->q[i].u = nullptr;
+    }
+    c->q_capacity = 0;
+    c->n_px = 0;
+}
+
+template <class T>
+int upload(rt_ctx *c, void *&dst, const T *src, size_t n) {
+    free_dev(dst);
+    size_t bytes = (n ? n : 1) * sizeof(T);
+    HIPCHK(c, hipMalloc(&dst, bytes));
+    if (n) HIPCHK(c, hipMemcpyAsync(dst, src, n * sizeof(T), hipMemcpyHostToDevice, c->stream));
+    return RT_OK;
+}
+
+RtPathQueue queue_view(const QueueMem &m, size_t cap) {
+    RtPathQueue q;
+    q.ox = m.f + 0 * cap; q.oy = m.f + 1 * cap; q.oz = m.f + 2 * cap;
+    q.dx = m.f + 3 * cap; q.dy = m.f + 4 * cap; q.dz = m.f + 5 * cap;
+    q.cr = m.f + 6 * cap; q.cg = m.f + 7 * cap; q.cb = m.f + 8 * cap;
+    q.rng = m.u; q.pixel = m.u + cap;
+    return q;
+}
+
+int ensure_queues(rt_ctx *c) {
+    if (c->q_capacity >= c->n_px && c->q[0].f) return RT_OK;
+    for (int i = 0; i < 2; ++i) {
+        void *p = c->q[i].f; free_dev(p);
+        p = c->q[i].u; free_dev(p);
+        HIPCHK(c, hipMalloc((void **)&c->q[i].f, c->n_px * 9 * sizeof(float)));
+        HIPCHK(c, hipMalloc((void **)&c->q[i].u, c->n_px * 2 * sizeof(uint32_t)));
+    }
+    c->q_capacity = c->n_px;
+    return RT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *rt_version(void) { return "ray-tracing_amd 0.1 (gfx950)"; }
+
+const char *rt_status_string(int s) {
+    switch (s) {
+        case RT_OK: return "ok";
+        case RT_NOT_READY: return "not ready (no scene or view yet; frame skipped)";
+        case RT_ERR_ARG: return "invalid argument";
+        case RT_ERR_HIP: return "HIP runtime error";
+        case RT_ERR_NO_GPU: return "no usable gfx950 GPU (this library has no CPU fallback)";
+        case RT_ERR_SCENE: return "inconsistent scene arrays";
+        case RT_ERR_OOM: return "out of device memory";
+        default: return "unknown status";
+    }
+}
+
+const char *rt_last_error(rt_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int rt_create(int device_ordinal, rt_ctx **out) {
+    if (!out) return fail(nullptr, RT_ERR_ARG, "rt_create: out is NULL");
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) return fail(nullptr, RT_ERR_NO_GPU, "rt_create: no HIP device", e);
+    if (device_ordinal < 0 || device_ordinal >= n) return fail(nullptr, RT_ERR_ARG, "rt_create: device ordinal out of range");
+    hipDeviceProp_t prop;
+    e = hipGetDeviceProperties(&prop, device_ordinal);
+    if (e != hipSuccess) return fail(nullptr, RT_ERR_HIP, "hipGetDeviceProperties", e);
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        std::string msg = std::string("rt_create: device is ") + prop.gcnArchName + ", kernels are built for gfx950 only";
+        return fail(nullptr, RT_ERR_NO_GPU, msg.c_str());
+    }
+    rt_ctx *c = new (std::nothrow) rt_ctx();
+    if (!c) return fail(nullptr, RT_ERR_OOM, "rt_create: host allocation failed");
+    c->device = device_ordinal;
+    int rc = RT_OK;
+    do {
+        if ((e = hipSetDevice(device_ordinal)) != hipSuccess) { rc = fail(nullptr, RT_ERR_HIP, "hipSetDevice", e); break; }
+        if ((e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking)) != hipSuccess) { rc = fail(nullptr, RT_ERR_HIP, "hipStreamCreate", e); break; }
+        c->stream = c->own_stream;
+        if ((e = hipMalloc((void **)&c->d_cnt, RT_CNT_N * sizeof(unsigned long long))) != hipSuccess) { rc = fail(nullptr, RT_ERR_HIP, "hipMalloc counters", e); break; }
+        if ((e = hipHostMalloc((void **)&c->h_cnt, RT_CNT_N * sizeof(unsigned long long), hipHostMallocDefault)) != hipSuccess) { rc = fail(nullptr, RT_ERR_HIP, "hipHostMalloc counters", e); break; }
+        std::memset(c->h_cnt, 0, RT_CNT_N * sizeof(unsigned long long));
+    } while (0);
+    if (rc != RT_OK) { rt_destroy(c); return rc; }
+    *out = c;
+    return RT_OK;
+}
+
+int rt_destroy(rt_ctx *c) {
+    if (!c) return RT_OK;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    free_scene(c);
+    free_frame(c);
+    if (c->d_cnt) (void)hipFree(c->d_cnt);
+    if (c->h_cnt) (void)hipHostFree(c->h_cnt);
+    for (hipEvent_t ev : c->ev) (void)hipEventDestroy(ev);
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    delete c;
+    return RT_OK;
+}
+
+int rt_set_stream(rt_ctx *c, void *hip_stream) {
+    if (!c) return RT_ERR_ARG;
+    (void)hipSetDevice(c->device);
+    if (c->stream) HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+    return RT_OK;
+}
+
+int rt_synchronize(rt_ctx *c) {
+    if (!c) return RT_ERR_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return RT_OK;
+}
+
+int rt_upload_scene(rt_ctx *c, const rt_triangle *tris, size_t n_tris, const rt_mesh_info *meshes, size_t n_meshes,
+                    const rt_vertex *verts, size_t n_verts, const rt_material *mats, size_t n_mats) {
+    if (!c) return RT_ERR_ARG;
+    if ((n_tris && !tris) || (n_meshes && !meshes) || (n_verts && !verts) || (n_mats && !mats))
+        return fail(c, RT_ERR_ARG, "rt_upload_scene: NULL array with non-zero count");
+    if (n_tris >= (1u << 28) || n_verts > 0xFFFFFFFFull || n_meshes > 0xFFFFFFFFull)
+        return fail(c, RT_ERR_ARG, "rt_upload_scene: scene too large (2^28 triangles max)");
+    // validate before touching the GPU: a kernel must never see an out-of-range index
+    uint64_t loop_items = 0;
+    for (size_t m = 0; m < n_meshes; ++m) {
+        uint64_t end = (uint64_t)meshes[m].first_tri + meshes[m].tri_count;
+        if (end > n_tris) return fail(c, RT_ERR_SCENE, "rt_upload_scene: mesh triangle range exceeds the triangle array");
+        loop_items += meshes[m].tri_count;
+    }
+    if (loop_items >= (1u << 28)) return fail(c, RT_ERR_ARG, "rt_upload_scene: too many (mesh, triangle) items");
+    for (size_t t = 0; t < n_tris; ++t)
+        for (int k = 0; k < 3; ++k)
+            if (tris[t].indices[k] >= n_verts) return fail(c, RT_ERR_SCENE, "rt_upload_scene: vertex index out of range");
+
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    free_scene(c);
+
+    RtBvhBuildResult bvh;
+    try {
+        rt_bvh_build(tris, n_tris, meshes, n_meshes, verts, n_verts, 0, &bvh);
+    } catch (const std::bad_alloc &) {
+        return fail(c, RT_ERR_OOM, "rt_upload_scene: host allocation failed in the BVH build");
+    }
+    if (bvh.max_depth >= RT_MAX_DEPTH) return fail(c, RT_ERR_SCENE, "rt_upload_scene: BVH depth guard violated");
+
+    int rc;
+    if ((rc = upload(c, c->d_nodes, bvh.nodes.data(), bvh.nodes.size())) != RT_OK) return rc;
+    if ((rc = upload(c, c->d_recs, bvh.recs.data(), bvh.recs.size())) != RT_OK) return rc;
+    if ((rc = upload(c, c->d_tris, tris, n_tris)) != RT_OK) return rc;
+    if ((rc = upload(c, c->d_meshes, meshes, n_meshes)) != RT_OK) return rc;
+    if ((rc = upload(c, c->d_verts, verts, n_verts)) != RT_OK) return rc;
+    if ((rc = upload(c, c->d_mats, mats, n_mats)) != RT_OK) return rc;
+    HIPCHK(c, hipStreamSynchronize(c->stream));   // host arrays are borrowed for this call only
+
+    c->S.nodes = (const RtBvhNode *)c->d_nodes;
+    c->S.recs = (const RtTriRecord *)c->d_recs;
+    c->S.tris = (const rt_triangle *)c->d_tris;
+    c->S.meshes = (const rt_mesh_info *)c->d_meshes;
+    c->S.verts = (const rt_vertex *)c->d_verts;
+    c->S.mats = (const rt_material *)c->d_mats;
+    c->S.n_nodes = (uint32_t)bvh.nodes.size();
+    c->S.n_recs = (uint32_t)bvh.recs.size();
+    c->S.n_tris = (uint32_t)n_tris;
+    c->S.n_meshes = (uint32_t)n_meshes;
+    c->S.n_verts = (uint32_t)n_verts;
+    c->S.n_mats = (uint32_t)n_mats;
+    c->info.n_nodes = bvh.nodes.size();
+    c->info.n_triangles = bvh.recs.size();
+    c->info.n_meshes = n_meshes;
+    c->info.n_vertices = n_verts;
+    c->info.node_bytes = sizeof(RtBvhNode);
+    c->info.tri_bytes = sizeof(RtTriRecord);
+    c->info.max_depth = bvh.max_depth;
+    c->info.max_leaf = bvh.max_leaf;
+    c->info.build_ms = bvh.build_ms;
+    c->info.sah_cost = bvh.sah_cost;
+    c->has_scene = true;
+    c->accum_samples = 0;
+    c->coverage_sig = 0;
+    return RT_OK;
+}
+
+int rt_set_view(rt_ctx *c, const float m[16], const float pos[3], uint32_t width, uint32_t height,
+                const uint32_t viewport[4]) {
+    if (!c || !m || !pos) return RT_ERR_ARG;
+    if (width == 0 || height == 0 || (uint64_t)width * height > (1ull << 31))
+        return fail(c, RT_ERR_ARG, "rt_set_view: bad target size");
+    uint32_t vx = 0, vy = 0, vw = width, vh = height;
+    if (viewport) {
+        vx = viewport[0]; vy = viewport[1]; vw = viewport[2]; vh = viewport[3];
+        if (vw == 0 || vh == 0 || (uint64_t)vx + vw > width || (uint64_t)vy + vh > height)
+            return fail(c, RT_ERR_ARG, "rt_set_view: viewport outside the target");
+    }
+    HIPCHK(c, hipSetDevice(c->device));
+    size_t n_px = (size_t)width * height;
+    if (n_px != c->n_px || c->V.width != width) {
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        free_frame(c);
+        HIPCHK(c, hipMalloc((void **)&c->d_rgba, n_px * 16));
+        HIPCHK(c, hipMalloc((void **)&c->d_accum, n_px * 16));
+        HIPCHK(c, hipMalloc((void **)&c->d_t, n_px * 4));
+        HIPCHK(c, hipMalloc((void **)&c->d_prim, n_px * 4));
+        c->n_px = n_px;
+        c->coverage_sig = 0;
+        c->accum_samples = 0;
+    }
+    if (c->has_view && (std::memcmp(c->V.m, m, 64) != 0 || std::memcmp(c->V.pos, pos, 12) != 0))
+        c->accum_dirty = true;       // accumulation resets on camera movement (intent of src/scene.rs:94-96)
+    std::memcpy(c->V.m, m, 64);
+    std::memcpy(c->V.pos, pos, 12);
+    c->V.width = width; c->V.height = height;
+    c->V.vx = vx; c->V.vy = vy; c->V.vw = vw; c->V.vh = vh;
+    c->has_view = true;
+    return RT_OK;
+}
+
+static int clear_outputs(rt_ctx *c) {
+    HIPCHK(c, hipMemsetAsync(c->d_rgba, 0, c->n_px * 16, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->d_t, 0, c->n_px * 4, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->d_prim, 0xFF, c->n_px * 4, c->stream));
+    return RT_OK;
+}
+
+int rt_render(rt_ctx *c, const rt_render_params *params) {
+    if (!c) return RT_ERR_ARG;
+    rt_render_params P;
+    std::memset(&P, 0, sizeof P);
+    if (params) {
+        if (params->struct_size != sizeof(rt_render_params)) return fail(c, RT_ERR_ARG, "rt_render: struct_size mismatch");
+        P = *params;
+    }
+    if (!c->has_scene || !c->has_view) return RT_NOT_READY;   // src/node.rs:52-56: skip silently
+    if (P.tile_size == 0) P.tile_size = 64;
+    if (P.tile_size % RT_WORK_TILE != 0 || P.tile_size > 4096) return fail(c, RT_ERR_ARG, "rt_render: tile_size must be a multiple of 16");
+    if (P.shard_count == 0) P.shard_count = 1;
+    if (P.shard_rank >= P.shard_count) return fail(c, RT_ERR_ARG, "rt_render: shard_rank >= shard_count");
+    HIPCHK(c, hipSetDevice(c->device));
+
+    RtShardDev sh;
+    sh.rank = P.shard_rank; sh.count = P.shard_count; sh.tile = P.tile_size;
+    sh.tiles_x = (c->V.vw + sh.tile - 1) / sh.tile;
+    sh.tiles_y = (c->V.vh + sh.tile - 1) / sh.tile;
+    uint32_t n_tiles = sh.tiles_x * sh.tiles_y;
+    sh.n_owned = n_tiles > sh.rank ? (n_tiles - sh.rank + sh.count - 1) / sh.count : 0;
+
+    // Pixels this call does not cover (outside the viewport, other ranks' tiles) must read as
+    // cleared; clear only when the coverage changes.
+    bool partial = sh.count > 1 || c->V.vw != c->V.width || c->V.vh != c->V.height;
+    uint64_t sig = 1ull | (((uint64_t)sh.rank << 1) ^ ((uint64_t)sh.count << 17) ^ ((uint64_t)sh.tile << 33) ^
+                   ((uint64_t)c->V.vx << 5) ^ ((uint64_t)c->V.vy << 21) ^ ((uint64_t)c->V.vw << 37) ^
+                   ((uint64_t)c->V.vh << 49) ^ (partial ? 0x8000000000000000ull : 0ull));
+    bool path = (P.flags & RT_FLAG_PATH_TRACE) != 0;
+    if (sig != c->coverage_sig) {
+        int rc = clear_outputs(c);
+        if (rc != RT_OK) return rc;
+        c->coverage_sig = sig;
+        c->accum_samples = 0;   // coverage changed: accumulation restarts (intent of src/scene.rs:94-96)
+        HIPCHK(c, hipMemsetAsync(c->d_accum, 0, c->n_px * 16, c->stream));
+    }
+    HIPCHK(c, hipMemsetAsync(c->d_cnt, 0, RT_CNT_N * sizeof(unsigned long long), c->stream));
+
+    bool timed = (P.flags & RT_FLAG_TIME_KERNELS) != 0;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    if (timed) {
+        if (c->ev_used + 2 > c->ev.size()) {
+            for (int i = 0; i < 2; ++i) {
+                hipEvent_t ev;
+                HIPCHK(c, hipEventCreate(&ev));
+                c->ev.push_back(ev);
+            }
+        }
+        ev0 = c->ev[c->ev_used]; ev1 = c->ev[c->ev_used + 1];
+    }
+
+    uint32_t launches = 0;
+    if (!path) {
+        if (timed) HIPCHK(c, hipEventRecord(ev0, c->stream));
+        HIPCHK(c, rtk_launch_primary(c->stream, c->S, c->V, sh, P.flags, c->d_rgba, c->d_prim, c->d_t, c->d_cnt));
+        launches = 1;
+        if (timed) HIPCHK(c, hipEventRecord(ev1, c->stream));
+    } else {
+        if (P.spp == 0) P.spp = 1;
+        if (P.max_segments == 0) P.max_segments = 4;   // reference shape: 4 segments (wgsl:185)
+        int rc = ensure_queues(c);
+        if (rc != RT_OK) return rc;
+        if (!(P.flags & RT_FLAG_ACCUMULATE) || c->accum_dirty) {
+            HIPCHK(c, hipMemsetAsync(c->d_accum, 0, c->n_px * 16, c->stream));
+            c->accum_samples = 0;
+            c->accum_dirty = false;
+        }
+        RtPathQueue qa = queue_view(c->q[0], c->q_capacity), qb = queue_view(c->q[1], c->q_capacity);
+        uint32_t cap = (uint32_t)((size_t)rtk_primary_blocks(sh) * RT_BLOCK);
+        if (cap > c->n_px) cap = (uint32_t)c->n_px;
+        if (timed) HIPCHK(c, hipEventRecord(ev0, c->stream));
+        for (uint32_t s = 0; s < P.spp; ++s) {
+            HIPCHK(c, hipMemsetAsync(c->d_cnt + RT_CNT_QUEUE_A, 0, 2 * sizeof(unsigned long long), c->stream));
+            HIPCHK(c, rtk_launch_path_start(c->stream, c->S, c->V, sh, P.flags, P.sample_first + s, P.seed, P.stream_id,
+                                            P.max_segments, c->d_accum, qa, c->d_cnt, RT_CNT_QUEUE_A));
+            ++launches;
+            int in = RT_CNT_QUEUE_A, out = RT_CNT_QUEUE_B;
+            for (uint32_t seg = 1; seg < P.max_segments; ++seg) {
+                HIPCHK(c, hipMemsetAsync(c->d_cnt + out, 0, sizeof(unsigned long long), c->stream));
+                HIPCHK(c, rtk_launch_path_bounce(c->stream, c->S, P.flags, cap, seg + 1 == P.max_segments, c->d_accum,
+                                                 in == RT_CNT_QUEUE_A ? qa : qb, in == RT_CNT_QUEUE_A ? qb : qa,
+                                                 c->d_cnt, in, out));
+                ++launches;
+                int tmp = in; in = out; out = tmp;
+            }
+        }
+        c->accum_samples += P.spp;
+        HIPCHK(c, rtk_launch_resolve(c->stream, c->d_accum, c->d_rgba, c->n_px, 0.0f, c->accum_samples));
+        if (timed) HIPCHK(c, hipEventRecord(ev1, c->stream));
+    }
+    if (timed) { c->ev_used += 2; c->counters.kernel_launches += launches; }
+    HIPCHK(c, hipMemcpyAsync(c->h_cnt, c->d_cnt, RT_CNT_N * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+    return RT_OK;
+}
+
+int rt_get_counters(rt_ctx *c, rt_counters *out) {
+    if (!c || !out) return RT_ERR_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    double ms = 0.0;
+    for (size_t i = 0; i + 1 < c->ev_used; i += 2) {
+        float t = 0.0f;
+        HIPCHK(c, hipEventElapsedTime(&t, c->ev[i], c->ev[i + 1]));
+        ms += t;
+    }
+    c->counters.rays_primary = c->h_cnt[RT_CNT_PRIMARY];
+    c->counters.rays_shadow = c->h_cnt[RT_CNT_SHADOW];
+    c->counters.rays_bounce = c->h_cnt[RT_CNT_BOUNCE];
+    c->counters.node_visits = c->h_cnt[RT_CNT_NODES];
+    c->counters.tri_tests = c->h_cnt[RT_CNT_TRIS];
+    c->counters.mesh_aabb_tests = c->h_cnt[RT_CNT_MESH];
+    c->counters.kernel_ms = ms;
+    *out = c->counters;
+    // timing accumulates between two rt_get_counters calls; ray counters are of the last render
+    c->ev_used = 0;
+    c->counters.kernel_launches = 0;
+    return RT_OK;
+}
+
+static int read_back(rt_ctx *c, void *dst, const void *src, size_t have, size_t want_bytes, const char *what) {
+    if (!c || !dst) return RT_ERR_ARG;
+    if (!c->has_view || !src) return RT_NOT_READY;
+    if (want_bytes != have) return fail(c, RT_ERR_ARG, what);
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemcpyAsync(dst, src, have, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return RT_OK;
+}
+
+int rt_read_radiance(rt_ctx *c, float *rgba, size_t n_floats) {
+    return read_back(c, rgba, c ? c->d_rgba : nullptr, c ? c->n_px * 16 : 0, n_floats * 4, "rt_read_radiance: size must be W*H*4 floats");
+}
+int rt_read_accumulation(rt_ctx *c, float *accum, size_t n_floats) {
+    return read_back(c, accum, c ? c->d_accum : nullptr, c ? c->n_px * 16 : 0, n_floats * 4, "rt_read_accumulation: size must be W*H*4 floats");
+}
+int rt_read_prim_ids(rt_ctx *c, uint32_t *prim, size_t n) {
+    return read_back(c, prim, c ? c->d_prim : nullptr, c ? c->n_px * 4 : 0, n * 4, "rt_read_prim_ids: size must be W*H");
+}
+int rt_read_hit_t(rt_ctx *c, float *t, size_t n) {
+    return read_back(c, t, c ? c->d_t : nullptr, c ? c->n_px * 4 : 0, n * 4, "rt_read_hit_t: size must be W*H");
+}
+int rt_read_bgra8_srgb(rt_ctx *c, uint8_t *bgra, size_t n_bytes) {
+    if (!c || !bgra) return RT_ERR_ARG;
+    if (!c->has_view) return RT_NOT_READY;
+    if (n_bytes != c->n_px * 4) return fail(c, RT_ERR_ARG, "rt_read_bgra8_srgb: size must be W*H*4 bytes");
+    HIPCHK(c, hipSetDevice(c->device));
+    if (!c->d_bgra) HIPCHK(c, hipMalloc((void **)&c->d_bgra, c->n_px * 4));
+    HIPCHK(c, rtk_launch_encode_bgra8(c->stream, c->d_rgba, c->d_bgra, c->n_px));
+    return read_back(c, bgra, c->d_bgra, c->n_px * 4, n_bytes, "");
+}
+
+int rt_device_buffers(rt_ctx *c, void **d_radiance, void **d_prim, void **d_accum) {
+    if (!c) return RT_ERR_ARG;
+    if (!c->has_view) return RT_NOT_READY;
+    if (d_radiance) *d_radiance = c->d_rgba;
+    if (d_prim) *d_prim = c->d_prim;
+    if (d_accum) *d_accum = c->d_accum;
+    return RT_OK;
+}
+
+int rt_resolve_accumulation(rt_ctx *c, uint32_t total_samples) {
+    if (!c || total_samples == 0) return RT_ERR_ARG;
+    if (!c->has_view) return RT_NOT_READY;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, rtk_launch_resolve(c->stream, c->d_accum, c->d_rgba, c->n_px, 0.0f, total_samples));
+    return RT_OK;
+}
+
+int rt_get_bvh_info(rt_ctx *c, rt_bvh_info *out) {
+    if (!c || !out) return RT_ERR_ARG;
+    if (!c->has_scene) return RT_NOT_READY;
+    *out = c->info;
+    return RT_OK;
+}
+
+int rt_read_bvh(rt_ctx *c, void *nodes, size_t node_bytes_total, void *tris, size_t tri_bytes_total) {
+    if (!c) return RT_ERR_ARG;
+    if (!c->has_scene) return RT_NOT_READY;
+    if (node_bytes_total != c->info.n_nodes * sizeof(RtBvhNode) || tri_bytes_total != c->info.n_triangles * sizeof(RtTriRecord))
+        return fail(c, RT_ERR_ARG, "rt_read_bvh: buffer sizes must match rt_get_bvh_info");
+    HIPCHK(c, hipSetDevice(c->device));
+    if (nodes && node_bytes_total) HIPCHK(c, hipMemcpyAsync(nodes, c->d_nodes, node_bytes_total, hipMemcpyDeviceToHost, c->stream));
+    if (tris && tri_bytes_total) HIPCHK(c, hipMemcpyAsync(tris, c->d_recs, tri_bytes_total, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return RT_OK;
+}
+
+}  // extern "C"

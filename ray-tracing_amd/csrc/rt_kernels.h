@@ -1,0 +1,32 @@
+// rt_kernels.h -- launchers of the HIP kernels (rt_kernels.hip).  Host-callable, asynchronous
+// on the given stream, no allocation, no synchronisation.
+#pragma once
+#include <hip/hip_runtime_api.h>
+#include "rt_layout.h"
+
+#define RT_BLOCK 256          // 4 waves; each wave owns one 8x8 pixel tile
+#define RT_WORK_TILE 16       // a block covers 16x16 pixels
+
+// Number of blocks a primary/path-start launch needs for this shard description.
+uint32_t rtk_primary_blocks(const RtShardDev &sh);
+
+// Live path of ray_tracing.wgsl:173-211 (+ build-defined shadow ray): ray gen, closest hit,
+// shade, outputs.  flags: RT_FLAG_* of rt_amd.h (SHADOW, NO_MESH_CULL, BRUTE_FORCE, COUNTERS).
+hipError_t rtk_launch_primary(hipStream_t st, const RtSceneDev &S, const RtViewDev &V, const RtShardDev &sh,
+                              uint32_t flags, float *rgba, uint32_t *prim, float *t,
+                              unsigned long long *counters);
+
+// Progressive path tracing (loop shape of ray_tracing.wgsl:180-202) as a wavefront:
+// start = ray gen + jitter + first segment; bounce = one further segment for every queued path.
+hipError_t rtk_launch_path_start(hipStream_t st, const RtSceneDev &S, const RtViewDev &V, const RtShardDev &sh,
+                                 uint32_t flags, uint32_t sample, uint32_t seed, uint32_t stream_id,
+                                 uint32_t max_segments, float *accum, RtPathQueue qout,
+                                 unsigned long long *counters, int qout_counter);
+hipError_t rtk_launch_path_bounce(hipStream_t st, const RtSceneDev &S, uint32_t flags, uint32_t capacity,
+                                  int is_last, float *accum, RtPathQueue qin, RtPathQueue qout,
+                                  unsigned long long *counters, int qin_counter, int qout_counter);
+
+hipError_t rtk_launch_resolve(hipStream_t st, const float *accum, float *rgba, size_t n_px, float inv_unused,
+                              uint32_t total_samples);
+hipError_t rtk_launch_encode_bgra8(hipStream_t st, const float *rgba, uint8_t *bgra, size_t n_px);
+hipError_t rtk_launch_fill_u32(hipStream_t st, uint32_t *p, uint32_t value, size_t n);

@@ -1,0 +1,585 @@
+// rt_kernels.hip -- hand-written HIP kernels for gfx950 (MI355X / CDNA4): the per-pixel hot
+// path of camms205/ray-tracing (assets/shaders/ray_tracing.wgsl:118-211), one thread per ray,
+// wave64 = one 8x8 pixel tile, BVH traversal with an LDS-resident per-lane stack.
+//
+// Float contract (must match oracle/rt_oracle.c bit for bit; built with -ffp-contract=off):
+//   dot = (x*x' + y*y') + z*z' ; cross component = p*q - r*s ; normalize = v / sqrt(dot(v,v));
+//   '/' and sqrtf are correctly rounded (hipcc default); min/max = fminf/fmaxf.
+#include <hip/hip_runtime.h>
+#include "rt_kernels.h"
+
+#define RT_STACK_LDS 24
+#define RT_STACK_OVF (RT_MAX_DEPTH + 2 - RT_STACK_LDS)
+#define RT_INF __builtin_huge_valf()
+
+struct f3 { float x, y, z; };
+__device__ __forceinline__ f3 F3(float x, float y, float z) { f3 r; r.x = x; r.y = y; r.z = z; return r; }
+__device__ __forceinline__ f3 sub(f3 a, f3 b) { return F3(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ f3 add(f3 a, f3 b) { return F3(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ f3 mul(f3 a, f3 b) { return F3(a.x * b.x, a.y * b.y, a.z * b.z); }
+__device__ __forceinline__ f3 scl(f3 a, float s) { return F3(a.x * s, a.y * s, a.z * s); }
+__device__ __forceinline__ float dot(f3 a, f3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+__device__ __forceinline__ f3 cross(f3 a, f3 b) {
+    return F3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+__device__ __forceinline__ f3 normalize(f3 a) {
+    float len = sqrtf(dot(a, a));
+    return F3(a.x / len, a.y / len, a.z / len);
+}
+
+// ---- A1 ray generation: ray_tracing.wgsl:174,176-177 ---------------------------------------
+__device__ __forceinline__ void ray_gen(const RtViewDev &V, uint32_t px, uint32_t py, f3 &o, f3 &d) {
+    float u = ((float)(px - V.vx) + 0.5f) / (float)V.vw;
+    float w = ((float)(py - V.vy) + 0.5f) / (float)V.vh;
+    float nx = u * 2.0f + -1.0f;
+    float ny = w * -2.0f + 1.0f;
+    float r[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        r[i] = ((V.m[0 + i] * nx + V.m[4 + i] * ny) + V.m[8 + i] * 0.0f) + V.m[12 + i] * 1.0f;
+    float len = sqrtf(((r[0] * r[0] + r[1] * r[1]) + r[2] * r[2]) + r[3] * r[3]);
+    d = F3(r[0] / len, r[1] / len, r[2] / len);
+    o = F3(V.pos[0], V.pos[1], V.pos[2]);
+}
+
+// ---- A3 ray/AABB cull: ray_tracing.wgsl:141-148 (inv = 1.0/dir, computed once per ray) --------
+__device__ __forceinline__ bool ray_aabb_ref(f3 o, f3 inv, f3 lb, f3 rt) {
+    f3 t1 = mul(sub(lb, o), inv);
+    f3 t2 = mul(sub(rt, o), inv);
+    float tmin = fmaxf(fmaxf(fminf(t1.x, t2.x), fminf(t1.y, t2.y)), fminf(t1.z, t2.z));
+    float tmax = fminf(fminf(fmaxf(t1.x, t2.x), fmaxf(t1.y, t2.y)), fmaxf(t1.z, t2.z));
+    return tmax >= tmin;
+}
+
+// ---- A4 ray/triangle: ray_tracing.wgsl:118-139, from a, ab, ac ----------------------------------
+__device__ __forceinline__ bool ray_tri(f3 o, f3 d, f3 a, f3 ab, f3 ac, float &dst, float &u, float &v) {
+    f3 norm = cross(ab, ac);
+    f3 ao = sub(o, a);
+    f3 dao = cross(ao, d);
+    float det = -dot(d, norm);
+    float inv_det = 1.0f / det;
+    dst = dot(ao, norm) * inv_det;
+    u = dot(ac, dao) * inv_det;
+    v = -dot(ab, dao) * inv_det;
+    float w = 1.0f - u - v;
+    return det >= 1e-6f && dst >= 0.0f && u >= 0.0f && v >= 0.0f && w >= 0.0f;
+}
+
+struct Hit {
+    float t, u, v;
+    uint32_t seq, tri, mesh;
+    bool hit;
+};
+
+struct Cnt { uint32_t nodes, tris, meshes; };
+
+// ---- BVH traversal (build-side design; reference src/bvh.rs:1 is empty) ----------------------
+// Closest hit with the reference's tie rule restated order-independently: among equal t the
+// lowest position in the (mesh, triangle) loop order wins (ray_tracing.wgsl:164).
+// The per-mesh AABB cull of wgsl:155 is applied to every accepted candidate, so a triangle whose
+// mesh box the ray misses is skipped exactly as the reference's outer loop skips it.
+// ANY: stop at the first accepted hit (shadow rays: hit_triangles(ray).hit).
+template <bool ANY, bool COUNT>
+__device__ __forceinline__ void traverse(const RtSceneDev &S, f3 o, f3 d, uint32_t flags, int *stk, Hit &h, Cnt &c) {
+    h.hit = false; h.t = RT_INF; h.u = 0.0f; h.v = 0.0f; h.seq = 0xFFFFFFFFu; h.tri = 0xFFFFFFFFu; h.mesh = 0;
+    if (S.n_nodes == 0) return;
+    const f3 inv = F3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    int ovf[RT_STACK_OVF];
+    int sp = 0;
+    int cur = 0;
+    uint32_t last_mesh = 0xFFFFFFFFu;
+    bool last_ok = true;
+    float limit = RT_INF;
+    for (;;) {
+        if (cur >= 0) {
+            const float4 *p = reinterpret_cast<const float4 *>(S.nodes + cur);
+            float4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3];
+            if (COUNT) c.nodes++;
+            // slabs of both children; (plane - o) * inv keeps inf/NaN handling conservative
+            float ax0 = (q0.x - o.x) * inv.x, ax1 = (q0.w - o.x) * inv.x;
+            float ay0 = (q0.y - o.y) * inv.y, ay1 = (q1.x - o.y) * inv.y;
+            float az0 = (q0.z - o.z) * inv.z, az1 = (q1.y - o.z) * inv.z;
+            float bx0 = (q1.z - o.x) * inv.x, bx1 = (q2.y - o.x) * inv.x;
+            float by0 = (q1.w - o.y) * inv.y, by1 = (q2.z - o.y) * inv.y;
+            float bz0 = (q2.x - o.z) * inv.z, bz1 = (q2.w - o.z) * inv.z;
+            float tmin0 = fmaxf(fmaxf(fminf(ax0, ax1), fminf(ay0, ay1)), fminf(az0, az1));
+            float tmax0 = fminf(fminf(fmaxf(ax0, ax1), fmaxf(ay0, ay1)), fmaxf(az0, az1));
+            float tmin1 = fmaxf(fmaxf(fminf(bx0, bx1), fminf(by0, by1)), fminf(bz0, bz1));
+            float tmax1 = fminf(fminf(fmaxf(bx0, bx1), fmaxf(by0, by1)), fmaxf(bz0, bz1));
+            tmax0 *= 1.0000005f; tmax1 *= 1.0000005f;   // robust slab test (2 ulp)
+            bool h0 = tmin0 <= tmax0 && tmax0 >= 0.0f && tmin0 <= limit;
+            bool h1 = tmin1 <= tmax1 && tmax1 >= 0.0f && tmin1 <= limit;
+            int c0 = __float_as_int(q3.x), c1 = __float_as_int(q3.y);
+            if (h0 && h1) {
+                bool swap = tmin1 < tmin0;
+                int nearc = swap ? c1 : c0, farc = swap ? c0 : c1;
+                if (sp < RT_STACK_LDS) stk[sp * RT_BLOCK] = farc;
+                else if (sp - RT_STACK_LDS < RT_STACK_OVF) ovf[sp - RT_STACK_LDS] = farc;
+                ++sp;
+                cur = nearc;
+                continue;
+            }
+            if (h0) { cur = c0; continue; }
+            if (h1) { cur = c1; continue; }
+        } else if (cur != RT_CHILD_NONE) {
+            uint32_t code = (uint32_t)(~cur);
+            uint32_t first = code >> 3, n = (code & 7u) + 1u;
+            for (uint32_t k = 0; k < n; ++k) {
+                const float4 *r = reinterpret_cast<const float4 *>(S.recs + first + k);
+                float4 r0 = r[0], r1 = r[1], r2 = r[2];
+                if (COUNT) c.tris++;
+                float dst, u, v;
+                bool ok = ray_tri(o, d, F3(r0.x, r0.y, r0.z), F3(r0.w, r1.x, r1.y), F3(r1.z, r1.w, r2.x), dst, u, v);
+                uint32_t seq = __float_as_uint(r2.w);
+                ok = ok && (dst < h.t || (dst == h.t && seq < h.seq));
+                if (ok) {
+                    uint32_t mesh = __float_as_uint(r2.z);
+                    if (!(flags & RT_FLAG_NO_MESH_CULL)) {
+                        if (mesh != last_mesh) {
+                            const float4 *mp = reinterpret_cast<const float4 *>(S.meshes + mesh);
+                            float4 m1 = mp[1], m2 = mp[2];
+                            last_ok = ray_aabb_ref(o, inv, F3(m1.x, m1.y, m1.z), F3(m2.x, m2.y, m2.z));
+                            last_mesh = mesh;
+                            if (COUNT) c.meshes++;
+                        }
+                        ok = last_ok;
+                    }
+                    if (ok) {
+                        h.hit = true; h.t = dst; h.u = u; h.v = v; h.seq = seq;
+                        h.tri = __float_as_uint(r2.y); h.mesh = mesh;
+                        // boxes are culled against a slightly relaxed bound so that a near-tie
+                        // (shared edge, coincident faces) is still visited and resolved by seq
+                        limit = dst * 1.00001f;
+                        if (ANY) return;
+                    }
+                }
+            }
+        }
+        if (sp == 0) break;
+        --sp;
+        cur = sp < RT_STACK_LDS ? stk[sp * RT_BLOCK] : ovf[sp - RT_STACK_LDS];
+    }
+}
+
+// ---- A5 reference-shaped closest hit (ray_tracing.wgsl:150-170): meshes, AABB cull, triangles ----
+template <bool ANY, bool COUNT>
+__device__ __forceinline__ void brute_force(const RtSceneDev &S, f3 o, f3 d, uint32_t flags, Hit &h, Cnt &c) {
+    h.hit = false; h.t = 0.0f; h.u = 0.0f; h.v = 0.0f; h.seq = 0xFFFFFFFFu; h.tri = 0xFFFFFFFFu; h.mesh = 0;
+    const f3 inv = F3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    for (uint32_t i = 0; i < S.n_meshes; ++i) {
+        const float4 *mp = reinterpret_cast<const float4 *>(S.meshes + i);
+        float4 m0 = mp[0], m1 = mp[1], m2 = mp[2];
+        if (COUNT) c.meshes++;
+        if (!(flags & RT_FLAG_NO_MESH_CULL) &&
+            !ray_aabb_ref(o, inv, F3(m1.x, m1.y, m1.z), F3(m2.x, m2.y, m2.z)))
+            continue;
+        uint32_t first = __float_as_uint(m0.x), count = __float_as_uint(m0.y);
+        for (uint32_t j = first; j < first + count; ++j) {
+            rt_triangle T = S.tris[j];
+            const float4 *pa = reinterpret_cast<const float4 *>(S.verts + T.indices[0]);
+            const float4 *pb = reinterpret_cast<const float4 *>(S.verts + T.indices[1]);
+            const float4 *pc = reinterpret_cast<const float4 *>(S.verts + T.indices[2]);
+            float4 a = pa[0], b = pb[0], cc = pc[0];
+            if (COUNT) c.tris++;
+            f3 A = F3(a.x, a.y, a.z);
+            float dst, u, v;
+            bool ok = ray_tri(o, d, A, sub(F3(b.x, b.y, b.z), A), sub(F3(cc.x, cc.y, cc.z), A), dst, u, v);
+            if (!ok) continue;
+            if (!h.hit || h.t > dst) {   // strict: the earlier triangle keeps a tie (wgsl:164)
+                h.hit = true; h.t = dst; h.u = u; h.v = v; h.tri = j; h.mesh = i;
+                if (ANY) return;
+            }
+        }
+    }
+}
+
+template <bool ANY, bool COUNT>
+__device__ __forceinline__ void trace(const RtSceneDev &S, f3 o, f3 d, uint32_t flags, int *stk, Hit &h, Cnt &c) {
+    if (flags & RT_FLAG_BRUTE_FORCE) brute_force<ANY, COUNT>(S, o, d, flags, h, c);
+    else traverse<ANY, COUNT>(S, o, d, flags, stk, h, c);
+}
+
+// point and interpolated vertex normal of an accepted hit: ray_tracing.wgsl:137-138
+__device__ __forceinline__ void finish_hit(const RtSceneDev &S, f3 o, f3 d, const Hit &h, f3 &point, f3 &normal,
+                                           uint32_t &material) {
+    rt_triangle T = S.tris[h.tri];
+    const float4 *pa = reinterpret_cast<const float4 *>(S.verts + T.indices[0]);
+    const float4 *pb = reinterpret_cast<const float4 *>(S.verts + T.indices[1]);
+    const float4 *pc = reinterpret_cast<const float4 *>(S.verts + T.indices[2]);
+    float4 na = pa[1], nb = pb[1], nc = pc[1];
+    float w = 1.0f - h.u - h.v;
+    point = add(o, scl(d, h.t));
+    f3 n = add(add(scl(F3(na.x, na.y, na.z), w), scl(F3(nb.x, nb.y, nb.z), h.u)), scl(F3(nc.x, nc.y, nc.z), h.v));
+    normal = normalize(n);
+    material = S.meshes[h.mesh].material;
+}
+
+// ---- pixel mapping: shard tiles -> 16x16 blocks -> 8x8 waves; XCD-aware block order -----------
+// Blocks b and b+8 share an XCD (and its 4 MiB L2) under round-robin dispatch, so the logical
+// block order gives every XCD one contiguous run of screen tiles: rays that walk the same BVH
+// subtrees hit the same L2.  Speed only, never correctness.
+__device__ __forceinline__ uint32_t xcd_remap(uint32_t b, uint32_t nb) {
+    uint32_t q = nb >> 3, r = nb & 7u, x = b & 7u;
+    uint32_t base = x < r ? x * (q + 1u) : r * (q + 1u) + (x - r) * q;
+    return base + (b >> 3);
+}
+
+__device__ __forceinline__ bool pixel_of_thread(const RtViewDev &V, const RtShardDev &sh, uint32_t nb,
+                                                uint32_t &px, uint32_t &py) {
+    uint32_t l = xcd_remap(blockIdx.x, nb);
+    uint32_t sub = sh.tile / RT_WORK_TILE;
+    uint32_t per_tile = sub * sub;
+    uint32_t k = l / per_tile, s = l % per_tile;
+    uint32_t g = sh.rank + k * (sh.count ? sh.count : 1u);
+    uint32_t gx = g % sh.tiles_x, gy = g / sh.tiles_x;
+    uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u;
+    uint32_t x = gx * sh.tile + (s % sub) * RT_WORK_TILE + (wave & 1u) * 8u + (lane & 7u);
+    uint32_t y = gy * sh.tile + (s / sub) * RT_WORK_TILE + (wave >> 1) * 8u + (lane >> 3);
+    px = V.vx + x; py = V.vy + y;
+    return x < V.vw && y < V.vh;
+}
+
+__device__ __forceinline__ void wave_count(unsigned long long *ctr, bool pred) {
+    unsigned long long m = __ballot(pred);
+    if (m && (threadIdx.x & 63u) == (uint32_t)__builtin_ctzll(m))
+        atomicAdd(ctr, (unsigned long long)__builtin_popcountll(m));
+}
+__device__ __forceinline__ void wave_sum(unsigned long long *ctr, uint32_t v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+    if ((threadIdx.x & 63u) == 0 && v) atomicAdd(ctr, (unsigned long long)v);
+}
+
+// ---- the live path: ray_tracing.wgsl:173-211 (+ shadow ray) ------------------
+template <bool COUNT>
+__global__ __launch_bounds__(RT_BLOCK) void k_primary(RtSceneDev S, RtViewDev V, RtShardDev sh, uint32_t nb,
+                                                      uint32_t flags, float4 *__restrict__ rgba,
+                                                      uint32_t *__restrict__ prim, float *__restrict__ tout,
+                                                      unsigned long long *__restrict__ counters) {
+    __shared__ int s_stack[RT_STACK_LDS * RT_BLOCK];
+    int *stk = s_stack + threadIdx.x;
+    uint32_t px, py;
+    bool active = pixel_of_thread(V, sh, nb, px, py);
+    Cnt c; c.nodes = 0; c.tris = 0; c.meshes = 0;
+    bool shadowed = false, did_shadow = false;
+    if (active) {
+        f3 o, d;
+        ray_gen(V, px, py, o, d);
+        Hit h;
+        trace<false, COUNT>(S, o, d, flags, stk, h, c);
+        float4 out = make_float4(0.0f, 0.0f, 0.0f, 0.0f);   // miss: vec4(0) (wgsl:210)
+        if (h.hit) {
+            f3 point, normal; uint32_t material;
+            finish_hit(S, o, d, h, point, normal, material);
+            if (material >= 100u) {                           // debug grey (wgsl:205-207)
+                float g = 0.5f + (float)(material - 100u) / 6.0f;
+                out = make_float4(g, g, g, g);
+            } else {
+                float ndl = dot(normal, F3(0.0f, 1.0f, 0.0f));
+                float4 col = material < S.n_mats ? *reinterpret_cast<const float4 *>(S.mats + material)
+                                                 : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                out = make_float4(col.x * ndl, col.y * ndl, col.z * ndl, col.w * ndl);
+            }
+            if (flags & RT_FLAG_SHADOW) {
+                f3 so = add(point, scl(normal, 1e-3f));
+                Hit sh_hit;
+                trace<true, COUNT>(S, so, F3(0.0f, 1.0f, 0.0f), flags, stk, sh_hit, c);
+                did_shadow = true;
+                shadowed = sh_hit.hit;
+                if (shadowed) out = make_float4(out.x * 0.25f, out.y * 0.25f, out.z * 0.25f, out.w * 0.25f);
+            }
+        }
+        size_t idx = (size_t)py * V.width + px;
+        rgba[idx] = out;
+        prim[idx] = h.hit ? h.tri : 0xFFFFFFFFu;
+        tout[idx] = h.hit ? h.t : 0.0f;
+    }
+    wave_count(counters + RT_CNT_PRIMARY, active);
+    wave_count(counters + RT_CNT_SHADOW, did_shadow);
+    if (COUNT) {
+        wave_sum(counters + RT_CNT_NODES, c.nodes);
+        wave_sum(counters + RT_CNT_TRIS, c.tris);
+        wave_sum(counters + RT_CNT_MESH, c.meshes);
+    }
+}
+
+// ---- A2 RNG: ray_tracing.wgsl:38-74 (integer core; deterministic log/cos) ------------------------
+__device__ __forceinline__ uint32_t next_random(uint32_t &state) {
+    state = state * 747796405u + 2891336453u;
+    uint32_t word = ((state >> ((state >> 28u) + 4u)) ^ state) * 277803737u;
+    return (word >> 22u) ^ word;
+}
+__device__ __forceinline__ float rt_rand(uint32_t &state) { return (float)next_random(state) / 4294967295.0f; }
+__device__ __forceinline__ uint32_t pcg_hash(uint32_t x) {
+    uint32_t st = x * 747796405u + 2891336453u;
+    uint32_t word = ((st >> ((st >> 28u) + 4u)) ^ st) * 277803737u;
+    return (word >> 22u) ^ word;
+}
+__device__ __forceinline__ uint32_t rt_seed(uint32_t pixel, uint32_t sample, uint32_t seed, uint32_t stream) {
+    uint32_t h = pcg_hash(pixel);
+    h = pcg_hash(h ^ (sample * 0x9E3779B9u + 0x7F4A7C15u));
+    h = pcg_hash(h ^ (seed + 0x85EBCA6Bu));
+    h = pcg_hash(h ^ (stream * 0xC2B2AE35u + 0x27D4EB2Fu));
+    return h;
+}
+// log / cos from +,-,*,/ and integer bit moves only: CPU oracle and GPU agree bit for bit.
+__device__ __forceinline__ float det_logf(float x) {
+    if (x != x || x < 0.0f) return __uint_as_float(0x7FC00000u);
+    if (x == 0.0f) return __uint_as_float(0xFF800000u);
+    uint32_t ix = __float_as_uint(x);
+    int k = 0;
+    if (ix < 0x00800000u) { x = x * 8388608.0f; ix = __float_as_uint(x); k = -23; }
+    if (ix >= 0x7F800000u) return x;
+    ix += 0x3F800000u - 0x3F3504F3u;
+    k += (int)(ix >> 23) - 127;
+    ix = (ix & 0x007FFFFFu) + 0x3F3504F3u;
+    float m = __uint_as_float(ix);
+    float f = m - 1.0f;
+    float s = f / (2.0f + f);
+    float z = s * s;
+    float w = z * z;
+    float t1 = w * (0.40000972152f + w * 0.24279078841f);
+    float t2 = z * (0.66666662693f + w * 0.28498786688f);
+    float R = t2 + t1;
+    float hfsq = 0.5f * f * f;
+    float dk = (float)k;
+    return dk * 6.9313812256e-01f + ((s * (hfsq + R) + dk * 9.0580006145e-06f) - hfsq + f);
+}
+__device__ __forceinline__ float det_cosf(float x) {
+    if (x != x || x - x != 0.0f) return __uint_as_float(0x7FC00000u);
+    float ax = x < 0.0f ? -x : x;
+    float q = floorf(ax * 0.63661977237f + 0.5f);
+    float r = ((ax - q * 1.5703125f) - q * 4.837512969970703125e-4f) - q * 7.54978995489188e-8f;
+    int n = (int)q & 3;
+    float r2 = r * r;
+    float sp = r + r * r2 * (-1.6666654611e-1f + r2 * (8.3321608736e-3f + r2 * -1.9515295891e-4f));
+    float cp = (1.0f - 0.5f * r2) + r2 * r2 * (4.166664568298827e-2f + r2 * (-1.388731625493765e-3f + r2 * 2.443315711809948e-5f));
+    return n == 0 ? cp : (n == 1 ? -sp : (n == 2 ? -cp : sp));
+}
+__device__ __forceinline__ float rand_norm(uint32_t &state) {   // wgsl:57-61
+    float theta = 2.0f * 3.1415926f * rt_rand(state);
+    float rho = sqrtf(-2.0f * det_logf(rt_rand(state)));
+    return rho * det_cosf(theta);
+}
+__device__ __forceinline__ f3 rand_hemi(uint32_t &state, f3 n) {  // wgsl:63-74
+    float x = rand_norm(state);
+    float y = rand_norm(state);
+    float z = rand_norm(state);
+    f3 dir = normalize(F3(x, y, z));
+    if (dot(n, dir) < 0.0f) dir = F3(-dir.x, -dir.y, -dir.z);
+    return dir;
+}
+
+// Wave-level compaction of surviving paths: one ballot, one atomic per wave.
+__device__ __forceinline__ uint32_t queue_slot(unsigned long long *ctr, bool alive) {
+    unsigned long long m = __ballot(alive);
+    uint32_t lane = threadIdx.x & 63u;
+    uint32_t base = 0;
+    if (m) {
+        int leader = __builtin_ctzll(m);
+        if ((int)lane == leader) base = (uint32_t)atomicAdd(ctr, (unsigned long long)__builtin_popcountll(m));
+        base = __shfl(base, leader);
+    }
+    return base + (uint32_t)__builtin_popcountll(m & ((1ull << lane) - 1ull));
+}
+
+// One segment of one path (body of the loop at ray_tracing.wgsl:185-201): trace, then either add
+// the sky term and end (miss) or scatter and keep going (hit).  Returns true if the path goes on.
+template <bool COUNT>
+__device__ __forceinline__ bool path_segment(const RtSceneDev &S, uint32_t flags, int *stk, f3 &o, f3 &d, f3 &col,
+                                             uint32_t &rng, float4 *acc, Cnt &c) {
+    Hit h;
+    trace<false, COUNT>(S, o, d, flags, stk, h, c);
+    if (h.hit) {
+        f3 point, normal; uint32_t material;
+        finish_hit(S, o, d, h, point, normal, material);
+        f3 nd = rand_hemi(rng, normal);
+        o = point; d = nd;
+        if (material < S.n_mats) {
+            float4 m = *reinterpret_cast<const float4 *>(S.mats + material);
+            col = mul(col, F3(m.x, m.y, m.z));
+        } else col = F3(0.0f, 0.0f, 0.0f);
+        return true;
+    }
+    f3 l = mul(F3(0.5f, 0.71f, 0.86f), col);      // sky (wgsl:197)
+    float4 a = *acc;
+    a.x = a.x + l.x; a.y = a.y + l.y; a.z = a.z + l.z;
+    *acc = a;
+    return false;
+}
+
+template <bool COUNT>
+__global__ __launch_bounds__(RT_BLOCK) void k_path_start(RtSceneDev S, RtViewDev V, RtShardDev sh, uint32_t nb,
+                                                         uint32_t flags, uint32_t sample, uint32_t seed,
+                                                         uint32_t stream_id, uint32_t max_segments,
+                                                         float4 *__restrict__ accum, RtPathQueue qo,
+                                                         unsigned long long *__restrict__ counters, int qo_ctr) {
+    __shared__ int s_stack[RT_STACK_LDS * RT_BLOCK];
+    int *stk = s_stack + threadIdx.x;
+    uint32_t px, py;
+    bool active = pixel_of_thread(V, sh, nb, px, py);
+    Cnt c; c.nodes = 0; c.tris = 0; c.meshes = 0;
+    bool alive = false;
+    f3 o, d, col; uint32_t rng = 0, pixel = 0;
+    if (active) {
+        pixel = py * V.width + px;
+        f3 d0;
+        ray_gen(V, px, py, o, d0);
+        rng = rt_seed(pixel, sample, seed, stream_id);
+        float jx = rt_rand(rng), jy = rt_rand(rng);
+        d = add(d0, scl(F3(jx, jy, 0.0f), 0.0015f));   // wgsl:184, not renormalised
+        col = F3(1.0f, 1.0f, 1.0f);
+        float4 *acc = accum + pixel;
+        float4 a = *acc; a.w = a.w + 1.0f; *acc = a;   // one more sample for this pixel
+        alive = path_segment<COUNT>(S, flags, stk, o, d, col, rng, acc, c) && max_segments > 1;
+    }
+    wave_count(counters + RT_CNT_PRIMARY, active);
+    uint32_t slot = queue_slot(counters + qo_ctr, alive);
+    if (alive) {
+        qo.ox[slot] = o.x; qo.oy[slot] = o.y; qo.oz[slot] = o.z;
+        qo.dx[slot] = d.x; qo.dy[slot] = d.y; qo.dz[slot] = d.z;
+        qo.cr[slot] = col.x; qo.cg[slot] = col.y; qo.cb[slot] = col.z;
+        qo.rng[slot] = rng; qo.pixel[slot] = pixel;
+    }
+    if (COUNT) {
+        wave_sum(counters + RT_CNT_NODES, c.nodes);
+        wave_sum(counters + RT_CNT_TRIS, c.tris);
+        wave_sum(counters + RT_CNT_MESH, c.meshes);
+    }
+}
+
+template <bool COUNT>
+__global__ __launch_bounds__(RT_BLOCK) void k_path_bounce(RtSceneDev S, uint32_t flags, int is_last,
+                                                          float4 *__restrict__ accum, RtPathQueue qi, RtPathQueue qo,
+                                                          unsigned long long *__restrict__ counters, int qi_ctr,
+                                                          int qo_ctr) {
+    __shared__ int s_stack[RT_STACK_LDS * RT_BLOCK];
+    int *stk = s_stack + threadIdx.x;
+    uint32_t n = (uint32_t)counters[qi_ctr];
+    uint32_t i = blockIdx.x * RT_BLOCK + threadIdx.x;
+    if (blockIdx.x * RT_BLOCK >= n) return;            // whole block past the queue end
+    bool active = i < n;
+    Cnt c; c.nodes = 0; c.tris = 0; c.meshes = 0;
+    bool alive = false;
+    f3 o, d, col; uint32_t rng = 0, pixel = 0;
+    if (active) {
+        o = F3(qi.ox[i], qi.oy[i], qi.oz[i]);
+        d = F3(qi.dx[i], qi.dy[i], qi.dz[i]);
+        col = F3(qi.cr[i], qi.cg[i], qi.cb[i]);
+        rng = qi.rng[i]; pixel = qi.pixel[i];
+        alive = path_segment<COUNT>(S, flags, stk, o, d, col, rng, accum + pixel, c) && !is_last;
+    }
+    wave_count(counters + RT_CNT_BOUNCE, active);
+    uint32_t slot = queue_slot(counters + qo_ctr, alive);
+    if (alive) {
+        qo.ox[slot] = o.x; qo.oy[slot] = o.y; qo.oz[slot] = o.z;
+        qo.dx[slot] = d.x; qo.dy[slot] = d.y; qo.dz[slot] = d.z;
+        qo.cr[slot] = col.x; qo.cg[slot] = col.y; qo.cb[slot] = col.z;
+        qo.rng[slot] = rng; qo.pixel[slot] = pixel;
+    }
+    if (COUNT) {
+        wave_sum(counters + RT_CNT_NODES, c.nodes);
+        wave_sum(counters + RT_CNT_TRIS, c.tris);
+        wave_sum(counters + RT_CNT_MESH, c.meshes);
+    }
+}
+
+// ---- A8 resolve: light / f32(samples) (ray_tracing.wgsl:212) ----------------------------------------
+__global__ void k_resolve(const float4 *__restrict__ accum, float4 *__restrict__ rgba, size_t n, float ns) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        float4 a = accum[i];
+        rgba[i] = make_float4(a.x / ns, a.y / ns, a.z / ns, a.w / ns);
+    }
+}
+
+// ---- presentation: clamp + sRGB encode to BGRA8 (src/pipeline.rs:56-60) ------------------------------
+__device__ __forceinline__ float srgb_oetf(float x) {
+    if (!(x > 0.0f)) return 0.0f;
+    if (x >= 1.0f) return 1.0f;
+    if (x <= 0.0031308f) return x * 12.92f;
+    return 1.055f * powf(x, 1.0f / 2.4f) - 0.055f;
+}
+__device__ __forceinline__ uint32_t unorm8(float x) {
+    if (!(x > 0.0f)) x = 0.0f;
+    if (x > 1.0f) x = 1.0f;
+    return (uint32_t)floorf(x * 255.0f + 0.5f);
+}
+__global__ void k_encode_bgra8(const float4 *__restrict__ rgba, uint32_t *__restrict__ bgra, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        float4 c = rgba[i];
+        bgra[i] = unorm8(srgb_oetf(c.z)) | (unorm8(srgb_oetf(c.y)) << 8) | (unorm8(srgb_oetf(c.x)) << 16) |
+                  (unorm8(c.w) << 24);
+    }
+}
+
+__global__ void k_fill_u32(uint32_t *p, uint32_t v, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) p[i] = v;
+}
+
+// ---- launchers --------------------------------------------------------------------------------------
+uint32_t rtk_primary_blocks(const RtShardDev &sh) {
+    uint32_t sub = sh.tile / RT_WORK_TILE;
+    return sh.n_owned * sub * sub;
+}
+
+hipError_t rtk_launch_primary(hipStream_t st, const RtSceneDev &S, const RtViewDev &V, const RtShardDev &sh,
+                              uint32_t flags, float *rgba, uint32_t *prim, float *t, unsigned long long *counters) {
+    uint32_t nb = rtk_primary_blocks(sh);
+    if (nb == 0) return hipSuccess;
+    if (flags & RT_FLAG_COUNTERS)
+        hipLaunchKernelGGL(k_primary<true>, dim3(nb), dim3(RT_BLOCK), 0, st, S, V, sh, nb, flags, (float4 *)rgba, prim, t, counters);
+    else
+        hipLaunchKernelGGL(k_primary<false>, dim3(nb), dim3(RT_BLOCK), 0, st, S, V, sh, nb, flags, (float4 *)rgba, prim, t, counters);
+    return hipGetLastError();
+}
+
+hipError_t rtk_launch_path_start(hipStream_t st, const RtSceneDev &S, const RtViewDev &V, const RtShardDev &sh,
+                                 uint32_t flags, uint32_t sample, uint32_t seed, uint32_t stream_id,
+                                 uint32_t max_segments, float *accum, RtPathQueue qout,
+                                 unsigned long long *counters, int qout_counter) {
+    uint32_t nb = rtk_primary_blocks(sh);
+    if (nb == 0) return hipSuccess;
+    if (flags & RT_FLAG_COUNTERS)
+        hipLaunchKernelGGL(k_path_start<true>, dim3(nb), dim3(RT_BLOCK), 0, st, S, V, sh, nb, flags, sample, seed, stream_id, max_segments, (float4 *)accum, qout, counters, qout_counter);
+    else
+        hipLaunchKernelGGL(k_path_start<false>, dim3(nb), dim3(RT_BLOCK), 0, st, S, V, sh, nb, flags, sample, seed, stream_id, max_segments, (float4 *)accum, qout, counters, qout_counter);
+    return hipGetLastError();
+}
+
+hipError_t rtk_launch_path_bounce(hipStream_t st, const RtSceneDev &S, uint32_t flags, uint32_t capacity,
+                                  int is_last, float *accum, RtPathQueue qin, RtPathQueue qout,
+                                  unsigned long long *counters, int qin_counter, int qout_counter) {
+    uint32_t nb = (capacity + RT_BLOCK - 1) / RT_BLOCK;
+    if (nb == 0) return hipSuccess;
+    if (flags & RT_FLAG_COUNTERS)
+        hipLaunchKernelGGL(k_path_bounce<true>, dim3(nb), dim3(RT_BLOCK), 0, st, S, flags, is_last, (float4 *)accum, qin, qout, counters, qin_counter, qout_counter);
+    else
+        hipLaunchKernelGGL(k_path_bounce<false>, dim3(nb), dim3(RT_BLOCK), 0, st, S, flags, is_last, (float4 *)accum, qin, qout, counters, qin_counter, qout_counter);
+    return hipGetLastError();
+}
+
+static uint32_t stream_grid(size_t n) {
+    size_t b = (n + 255) / 256;
+    return (uint32_t)(b < 1 ? 1 : (b > 2048 ? 2048 : b));
+}
+hipError_t rtk_launch_resolve(hipStream_t st, const float *accum, float *rgba, size_t n_px, float, uint32_t total_samples) {
+    if (n_px == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_resolve, dim3(stream_grid(n_px)), dim3(256), 0, st, (const float4 *)accum, (float4 *)rgba, n_px, (float)total_samples);
+    return hipGetLastError();
+}
+hipError_t rtk_launch_encode_bgra8(hipStream_t st, const float *rgba, uint8_t *bgra, size_t n_px) {
+    if (n_px == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_encode_bgra8, dim3(stream_grid(n_px)), dim3(256), 0, st, (const float4 *)rgba, (uint32_t *)bgra, n_px);
+    return hipGetLastError();
+}
+hipError_t rtk_launch_fill_u32(hipStream_t st, uint32_t *p, uint32_t value, size_t n) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_fill_u32, dim3(stream_grid(n)), dim3(256), 0, st, p, value, n);
+    return hipGetLastError();
+}

@@ -1,0 +1,467 @@
+// ray_tracing.cpp -- host-side mirror of the reference's plugin interface (see ray_tracing.hpp).
+// Built with -ffp-contract=off: the arithmetic here is part of the parity contract with
+// oracle/rt_oracle.c (prepare_meshinfo restatement).
+#include "ray_tracing.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <map>
+#include <stdexcept>
+#include <tuple>
+
+namespace ray_tracing {
+
+namespace {
+inline Vec3 v3(float x, float y, float z) { Vec3 r; r.x = x; r.y = y; r.z = z; return r; }
+inline Vec3 add(Vec3 a, Vec3 b) { return v3(a.x + b.x, a.y + b.y, a.z + b.z); }
+inline Vec3 sub(Vec3 a, Vec3 b) { return v3(a.x - b.x, a.y - b.y, a.z - b.z); }
+inline Vec3 scl(Vec3 a, float s) { return v3(a.x * s, a.y * s, a.z * s); }
+inline float dot(Vec3 a, Vec3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+inline Vec3 cross(Vec3 a, Vec3 b) {
+    return v3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+inline Vec3 normalize(Vec3 a) { float l = std::sqrt(dot(a, a)); return v3(a.x / l, a.y / l, a.z / l); }
+
+// glam Mat3::from_quat (glam 0.27.0, Cargo.lock:2129-2130; un-vendored, restated)
+void mat3_from_quat(Quat q, Vec3 &c0, Vec3 &c1, Vec3 &c2) {
+    float x2 = q.x + q.x, y2 = q.y + q.y, z2 = q.z + q.z;
+    float xx = q.x * x2, xy = q.x * y2, xz = q.x * z2, yy = q.y * y2, yz = q.y * z2, zz = q.z * z2;
+    float wx = q.w * x2, wy = q.w * y2, wz = q.w * z2;
+    c0 = v3(1.0f - (yy + zz), xy + wz, xz - wy);
+    c1 = v3(xy - wz, 1.0f - (xx + zz), yz + wx);
+    c2 = v3(xz + wy, yz - wx, 1.0f - (xx + yy));
+}
+inline Vec3 mat3_mul(Vec3 c0, Vec3 c1, Vec3 c2, Vec3 p) { return add(add(scl(c0, p.x), scl(c1, p.y)), scl(c2, p.z)); }
+inline Vec3 vabs(Vec3 a) { return v3(std::fabs(a.x), std::fabs(a.y), std::fabs(a.z)); }
+
+struct SplitMix64 {
+    uint64_t s;
+    explicit SplitMix64(uint64_t seed) : s(seed) {}
+    uint64_t next() {
+        uint64_t z = (s += 0x9E3779B97F4A7C15ull);
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        return z ^ (z >> 31);
+    }
+    float uniform(float lo, float hi) {   // 24-bit mantissa, [lo, hi)
+        float u = (float)(next() >> 40) * (1.0f / 16777216.0f);
+        return lo + (hi - lo) * u;
+    }
+};
+}  // namespace
+
+// ---- glam restatements -----------------------------------------------------------------------
+Quat quat_from_axis_angle(Vec3 axis, float angle) {
+    float s = std::sin(angle * 0.5f), c = std::cos(angle * 0.5f);
+    Quat q; q.x = axis.x * s; q.y = axis.y * s; q.z = axis.z * s; q.w = c;
+    return q;
+}
+Quat quat_mul(Quat a, Quat b) {
+    Quat q;
+    q.x = a.w * b.x + a.x * b.w + a.y * b.z - a.z * b.y;
+    q.y = a.w * b.y - a.x * b.z + a.y * b.w + a.z * b.x;
+    q.z = a.w * b.z + a.x * b.y - a.y * b.x + a.z * b.w;
+    q.w = a.w * b.w - a.x * b.x - a.y * b.y - a.z * b.z;
+    return q;
+}
+Vec3 quat_rotate(Quat q, Vec3 r) {   // glam Quat * Vec3 (scalar path)
+    Vec3 b = v3(q.x, q.y, q.z);
+    float b2 = dot(b, b);
+    return add(add(scl(r, q.w * q.w - b2), scl(b, dot(r, b) * 2.0f)), scl(cross(b, r), q.w * 2.0f));
+}
+static Quat quat_from_axes(Vec3 x, Vec3 y, Vec3 z) {   // glam Quat::from_rotation_axes
+    float m00 = x.x, m01 = x.y, m02 = x.z, m10 = y.x, m11 = y.y, m12 = y.z, m20 = z.x, m21 = z.y, m22 = z.z;
+    Quat q;
+    if (m22 <= 0.0f) {
+        float dif10 = m11 - m00, omm22 = 1.0f - m22;
+        if (dif10 <= 0.0f) {
+            float four_xsq = omm22 - dif10, inv4x = 0.5f / std::sqrt(four_xsq);
+            q.x = four_xsq * inv4x; q.y = (m01 + m10) * inv4x; q.z = (m02 + m20) * inv4x; q.w = (m12 - m21) * inv4x;
+        } else {
+            float four_ysq = omm22 + dif10, inv4y = 0.5f / std::sqrt(four_ysq);
+            q.x = (m01 + m10) * inv4y; q.y = four_ysq * inv4y; q.z = (m12 + m21) * inv4y; q.w = (m20 - m02) * inv4y;
+        }
+    } else {
+        float sum10 = m11 + m00, opm22 = 1.0f + m22;
+        if (sum10 <= 0.0f) {
+            float four_zsq = opm22 - sum10, inv4z = 0.5f / std::sqrt(four_zsq);
+            q.x = (m02 + m20) * inv4z; q.y = (m12 + m21) * inv4z; q.z = four_zsq * inv4z; q.w = (m01 - m10) * inv4z;
+        } else {
+            float four_wsq = opm22 + sum10, inv4w = 0.5f / std::sqrt(four_wsq);
+            q.x = (m12 - m21) * inv4w; q.y = (m20 - m02) * inv4w; q.z = (m01 - m10) * inv4w; q.w = four_wsq * inv4w;
+        }
+    }
+    return q;
+}
+GlobalTransform looking_at(Vec3 eye, Vec3 target, Vec3 up) {   // Transform::looking_at, src/main.rs:61
+    Vec3 back = normalize(sub(eye, target));     // camera looks down -Z
+    Vec3 right = normalize(cross(up, back));
+    Vec3 upv = cross(back, right);
+    GlobalTransform t;
+    t.translation = eye;
+    t.rotation = quat_from_axes(right, upv, back);
+    return t;
+}
+
+// bevy View: world_from_clip = world_from_view * inverse(clip_from_view), with
+// clip_from_view = Mat4::perspective_infinite_reverse_rh(fov_y, aspect, near).  Its inverse maps
+// clip (x, y, z, w) to view (x*aspect/f, y/f, -w, z/near), f = 1/tan(fov_y/2).
+View extract_view(const Camera &cam) {
+    View v{};
+    uint32_t w = cam.has_viewport ? cam.viewport.w : cam.width;
+    uint32_t h = cam.has_viewport ? cam.viewport.h : cam.height;
+    float aspect = (float)w / (float)h;
+    float f = 1.0f / std::tan(0.5f * cam.fov_y);
+    Vec3 c0, c1, c2;
+    mat3_from_quat(cam.transform.rotation, c0, c1, c2);
+    Vec3 t = cam.transform.translation;
+    // inverse projection columns (view-space 4-vectors): col0=(a/f,0,0,0) col1=(0,1/f,0,0)
+    // col2=(0,0,0,1/near) col3=(0,0,-1,0); world_from_view = [c0 c1 c2 t; 0 0 0 1]
+    float ix = aspect / f, iy = 1.0f / f, iw = 1.0f / cam.near;
+    float *m = v.world_from_clip;
+    m[0] = c0.x * ix; m[1] = c0.y * ix; m[2] = c0.z * ix; m[3] = 0.0f;
+    m[4] = c1.x * iy; m[5] = c1.y * iy; m[6] = c1.z * iy; m[7] = 0.0f;
+    m[8] = t.x * iw;  m[9] = t.y * iw;  m[10] = t.z * iw; m[11] = iw;
+    m[12] = -c2.x;    m[13] = -c2.y;    m[14] = -c2.z;    m[15] = 0.0f;
+    v.world_position[0] = t.x; v.world_position[1] = t.y; v.world_position[2] = t.z;
+    v.width = cam.width; v.height = cam.height;
+    v.has_viewport = cam.has_viewport; v.viewport = cam.viewport;
+    return v;
+}
+
+// ---- meshes ---------------------------------------------------------------------------------------
+Aabb compute_aabb(const Mesh &m) {   // bevy Mesh::compute_aabb: centre/half-extents of the positions
+    Aabb a;
+    if (m.positions.empty()) return a;
+    Vec3 lo = m.positions[0], hi = m.positions[0];
+    for (const Vec3 &p : m.positions) {
+        lo = v3(std::min(lo.x, p.x), std::min(lo.y, p.y), std::min(lo.z, p.z));
+        hi = v3(std::max(hi.x, p.x), std::max(hi.y, p.y), std::max(hi.z, p.z));
+    }
+    a.center = scl(add(lo, hi), 0.5f);
+    a.half_extents = scl(sub(hi, lo), 0.5f);
+    return a;
+}
+
+Mesh cuboid_mesh(float sx, float sy, float sz) {   // stands in for bevy Cuboid::new(..).mesh(): 24 verts, 12 tris
+    Mesh m;
+    float hx = sx * 0.5f, hy = sy * 0.5f, hz = sz * 0.5f;
+    struct Face { Vec3 n, u, v; };
+    const Face faces[6] = {
+        {v3(0, 0, 1), v3(1, 0, 0), v3(0, 1, 0)},  {v3(0, 0, -1), v3(-1, 0, 0), v3(0, 1, 0)},
+        {v3(1, 0, 0), v3(0, 0, -1), v3(0, 1, 0)}, {v3(-1, 0, 0), v3(0, 0, 1), v3(0, 1, 0)},
+        {v3(0, 1, 0), v3(1, 0, 0), v3(0, 0, -1)}, {v3(0, -1, 0), v3(1, 0, 0), v3(0, 0, 1)},
+    };
+    Vec3 h = v3(hx, hy, hz);
+    for (const Face &f : faces) {
+        uint32_t base = (uint32_t)m.positions.size();
+        const float su[4] = {-1, 1, 1, -1}, sv[4] = {-1, -1, 1, 1};
+        for (int k = 0; k < 4; ++k) {
+            Vec3 d = add(add(f.n, scl(f.u, su[k])), scl(f.v, sv[k]));
+            m.positions.push_back(v3(d.x * h.x, d.y * h.y, d.z * h.z));
+            m.normals.push_back(f.n);
+        }
+        const uint32_t idx[6] = {0, 1, 2, 2, 3, 0};   // CCW seen from outside (u x v = n)
+        for (uint32_t i : idx) m.indices.push_back(base + i);
+    }
+    return m;
+}
+
+Mesh plane_mesh(float half_x, float half_z) {   // Plane3d::new(Vec3::Y, half_size): 4 verts, 2 tris, facing +Y
+    Mesh m;
+    m.positions = {v3(-half_x, 0, -half_z), v3(-half_x, 0, half_z), v3(half_x, 0, half_z), v3(half_x, 0, -half_z)};
+    m.normals.assign(4, v3(0, 1, 0));
+    m.indices = {0, 1, 2, 2, 3, 0};
+    return m;
+}
+
+Mesh icosphere_mesh(float radius, uint32_t subdivisions) {
+    // Each icosahedron face is cut into (s+1)^2 triangles, s = subdivisions, and the grid points
+    // are pushed onto the sphere: 20(s+1)^2 triangles, 10(s+1)^2+2 vertices (s=5: 720 / 362, the
+    // counts of bevy's Sphere::mesh() default).  Vertex order is this generator's own.
+    Mesh m;
+    const float t = (1.0f + std::sqrt(5.0f)) * 0.5f;
+    Vec3 base[12] = {v3(-1, t, 0), v3(1, t, 0), v3(-1, -t, 0), v3(1, -t, 0), v3(0, -1, t), v3(0, 1, t),
+                     v3(0, -1, -t), v3(0, 1, -t), v3(t, 0, -1), v3(t, 0, 1), v3(-t, 0, -1), v3(-t, 0, 1)};
+    for (Vec3 &b : base) b = normalize(b);
+    const int F[20][3] = {{0, 11, 5}, {0, 5, 1}, {0, 1, 7}, {0, 7, 10}, {0, 10, 11}, {1, 5, 9}, {5, 11, 4},
+                          {11, 10, 2}, {10, 7, 6}, {7, 1, 8}, {3, 9, 4}, {3, 4, 2}, {3, 2, 6}, {3, 6, 8},
+                          {3, 8, 9}, {4, 9, 5}, {2, 4, 11}, {6, 2, 10}, {8, 6, 7}, {9, 8, 1}};
+    const uint32_t N = subdivisions + 1;
+    std::map<std::tuple<int, int, int, int>, uint32_t> shared;   // corner / edge points
+    auto emit = [&](Vec3 dir) {
+        Vec3 n = normalize(dir);
+        m.normals.push_back(n);
+        m.positions.push_back(scl(n, radius));
+        return (uint32_t)(m.positions.size() - 1);
+    };
+    for (int f = 0; f < 20; ++f) {
+        int A = F[f][0], B = F[f][1], C = F[f][2];
+        if (dot(cross(sub(base[B], base[A]), sub(base[C], base[A])), add(add(base[A], base[B]), base[C])) < 0.0f)
+            std::swap(B, C);
+        std::vector<uint32_t> grid((N + 1) * (N + 1), 0xFFFFFFFFu);
+        for (uint32_t i = 0; i <= N; ++i) {        // weight of B
+            for (uint32_t j = 0; i + j <= N; ++j) {  // weight of C
+                uint32_t k = N - i - j;              // weight of A
+                std::tuple<int, int, int, int> key;
+                bool is_shared = true;
+                if (k == N) key = std::make_tuple(A, A, 0, 0);
+                else if (i == N) key = std::make_tuple(B, B, 0, 0);
+                else if (j == N) key = std::make_tuple(C, C, 0, 0);
+                else if (j == 0) key = A < B ? std::make_tuple(A, B, (int)i, 1) : std::make_tuple(B, A, (int)k, 1);
+                else if (i == 0) key = A < C ? std::make_tuple(A, C, (int)j, 1) : std::make_tuple(C, A, (int)k, 1);
+                else if (k == 0) key = B < C ? std::make_tuple(B, C, (int)j, 1) : std::make_tuple(C, B, (int)i, 1);
+                else is_shared = false;
+                uint32_t idx;
+                if (is_shared) {
+                    auto it = shared.find(key);
+                    if (it != shared.end()) idx = it->second;
+                    else {
+                        // point on the edge P->Q at step s/N from P, computed from the edge's
+                        // endpoints only so both faces sharing the edge get the same vertex
+                        int P = std::get<0>(key), Q = std::get<1>(key), s = std::get<2>(key);
+                        Vec3 dir = P == Q ? base[P]
+                                          : add(scl(base[P], (float)(N - (uint32_t)s) / (float)N), scl(base[Q], (float)s / (float)N));
+                        idx = emit(dir);
+                        shared[key] = idx;
+                    }
+                } else {
+                    Vec3 dir = add(add(scl(base[A], (float)k / (float)N), scl(base[B], (float)i / (float)N)),
+                                   scl(base[C], (float)j / (float)N));
+                    idx = emit(dir);
+                }
+                grid[i * (N + 1) + j] = idx;
+            }
+        }
+        for (uint32_t i = 0; i < N; ++i) {
+            for (uint32_t j = 0; i + j < N; ++j) {
+                uint32_t p00 = grid[i * (N + 1) + j], p10 = grid[(i + 1) * (N + 1) + j], p01 = grid[i * (N + 1) + j + 1];
+                m.indices.push_back(p00); m.indices.push_back(p10); m.indices.push_back(p01);
+                if (i + j + 1 < N) {
+                    uint32_t p11 = grid[(i + 1) * (N + 1) + j + 1];
+                    m.indices.push_back(p10); m.indices.push_back(p11); m.indices.push_back(p01);
+                }
+            }
+        }
+    }
+    return m;
+}
+
+// ---- P1 prepare_meshinfo: src/ray_tracing.rs:98-169, quirks kept ---------------------------------------
+void prepare_meshinfo(World &world) {
+    RayTracingInfo info = world.ray_tracing_info;   // `ray_tracing_info.clone()` keeps `count` (:112)
+    info.vertices.clear(); info.triangles.clear(); info.meshes.clear(); info.materials.clear();
+    uint32_t material_index = 0;
+    for (const Entity &e : world.entities) {
+        if (e.mesh < 0 || (size_t)e.mesh >= world.meshes.size() || e.material < 0 ||
+            (size_t)e.material >= world.materials.size())
+            throw std::runtime_error("prepare_meshinfo: dangling asset handle (reference: unwrap() panic, src/ray_tracing.rs:120-121)");
+        const Mesh &mesh = world.meshes[e.mesh];
+        const StandardMaterial &mat = world.materials[e.material];
+        SimpleMaterial sm;
+        std::memcpy(sm.color, mat.base_color_linear, 16);
+        info.materials.push_back(sm);                 // pushed BEFORE the attribute check (:122)
+        if (!mesh.has_positions || !mesh.has_normals) {
+            world.log += "Mesh missing attribute\n";  // (:127), then `continue`: no MeshInfo, no index bump
+            continue;
+        }
+        size_t vertices_len = info.vertices.size();
+        const GlobalTransform &T = e.transform;
+        Vec3 c0, c1, c2;
+        mat3_from_quat(T.rotation, c0, c1, c2);
+        Vec3 m0 = scl(c0, T.scale.x), m1 = scl(c1, T.scale.y), m2 = scl(c2, T.scale.z);
+        size_t nv = std::min(mesh.positions.size(), mesh.normals.size());   // zip() stops at the shorter
+        for (size_t i = 0; i < nv; ++i) {
+            Vertex v;
+            std::memset(&v, 0, sizeof v);
+            Vec3 p = add(mat3_mul(m0, m1, m2, mesh.positions[i]), T.translation);   // transform_point (:137)
+            Vec3 n = quat_rotate(T.rotation, mesh.normals[i]);                      // rotate only (:139-141)
+            v.pos[0] = p.x; v.pos[1] = p.y; v.pos[2] = p.z;
+            v.norm[0] = n.x; v.norm[1] = n.y; v.norm[2] = n.z;
+            info.vertices.push_back(v);
+        }
+        if (!mesh.has_indices)
+            throw std::runtime_error("prepare_meshinfo: mesh has no indices (reference: unwrap() panic, src/ray_tracing.rs:145)");
+        size_t len = mesh.indices.size();
+        // Cuboid::from_size(half_extents * 2).aabb_3d(translate, rotate) (:148-149): the Aabb's
+        // centre and the transform's scale are ignored
+        Vec3 he = v3((e.aabb.half_extents.x * 2.0f) / 2.0f, (e.aabb.half_extents.y * 2.0f) / 2.0f,
+                     (e.aabb.half_extents.z * 2.0f) / 2.0f);
+        Vec3 half = mat3_mul(vabs(c0), vabs(c1), vabs(c2), he);
+        MeshInfo mi;
+        std::memset(&mi, 0, sizeof mi);
+        mi.first_tri = (uint32_t)info.triangles.size();
+        mi.tri_count = (uint32_t)len / 3u;
+        mi.material = material_index;
+        Vec3 lo = sub(T.translation, half), hi = add(T.translation, half);
+        mi.aabb_min[0] = lo.x; mi.aabb_min[1] = lo.y; mi.aabb_min[2] = lo.z;
+        mi.aabb_max[0] = hi.x; mi.aabb_max[1] = hi.y; mi.aabb_max[2] = hi.z;
+        info.meshes.push_back(mi);
+        material_index += 1;
+        for (size_t i = 0; i + 2 < len; i += 3) {     // tuples() drops a trailing partial triple (:161)
+            Triangle t;
+            t.indices[0] = (uint32_t)(mesh.indices[i + 0] + vertices_len);
+            t.indices[1] = (uint32_t)(mesh.indices[i + 1] + vertices_len);
+            t.indices[2] = (uint32_t)(mesh.indices[i + 2] + vertices_len);
+            info.triangles.push_back(t);
+        }
+    }
+    world.ray_tracing_info = std::move(info);         // commands.insert_resource (:168)
+}
+
+// ---- scenes ---------------------------------------------------------------------------------------------
+static int add_mesh(World &w, Mesh m) { w.meshes.push_back(std::move(m)); return (int)w.meshes.size() - 1; }
+static int add_material(World &w, float r, float g, float b, float a) {
+    StandardMaterial m; m.base_color_linear[0] = r; m.base_color_linear[1] = g; m.base_color_linear[2] = b; m.base_color_linear[3] = a;
+    w.materials.push_back(m);
+    return (int)w.materials.size() - 1;
+}
+static Entity &spawn(World &w, int mesh, int material, GlobalTransform t) {
+    Entity e;
+    e.mesh = mesh; e.material = material; e.transform = t;
+    e.aabb = compute_aabb(w.meshes[mesh]);
+    w.entities.push_back(e);
+    return w.entities.back();
+}
+
+void spawn_default_scene(World &world) {   // src/main.rs:51-117
+    int blue = add_material(world, 0.0f, 0.0f, 1.0f, 1.0f);   // LinearRgba::BLUE (:56)
+    int red = add_material(world, 1.0f, 0.0f, 0.0f, 1.0f);    // Color::srgb(1,0,0) -> linear (1,0,0) (:57)
+    world.camera.transform = looking_at(v3(0.0f, 3.0f, 5.0f), v3(0, 0, 0), v3(0, 1, 0));   // (:61)
+    world.camera.ray_tracing_graph = true;                                                  // (:60)
+    GlobalTransform t;
+    t.rotation = quat_from_axis_angle(v3(1, 0, 0), 45.0f * 3.14159265358979323846f / 180.0f);   // (:71-74)
+    spawn(world, add_mesh(world, cuboid_mesh(1.0f, 1.0f, 1.0f)), blue, t).rotate_tag = true;      // (:67-78)
+    spawn(world, add_mesh(world, plane_mesh(5.0f, 5.0f)), blue, GlobalTransform());               // (:79-83)
+    const float xs[4] = {1.0f, -1.0f, 1.0f, -1.0f}, zs[4] = {1.0f, 1.0f, -1.0f, -1.0f};          // (:84-107)
+    for (int i = 0; i < 4; ++i) {
+        GlobalTransform s;
+        s.translation = v3(xs[i], 0.5f, zs[i]);
+        spawn(world, add_mesh(world, icosphere_mesh(0.5f, 5)), red, s);   // each spawn adds its own mesh asset
+    }
+    // the PointLight of :108-116 is not consumed by the ray tracer
+}
+
+void spawn_sphere_field(World &world, uint32_t n, uint64_t seed, uint32_t subdivisions) {
+    SplitMix64 rng(seed);
+    int ground = add_material(world, 0.5f, 0.5f, 0.5f, 1.0f);
+    spawn(world, add_mesh(world, plane_mesh(60.0f, 60.0f)), ground, GlobalTransform());
+    for (uint32_t i = 0; i < n; ++i) {
+        float cx = rng.uniform(-50.0f, 50.0f), cy = rng.uniform(0.0f, 20.0f), cz = rng.uniform(-50.0f, 50.0f);
+        float r = rng.uniform(0.2f, 0.8f);
+        float cr = rng.uniform(0.1f, 1.0f), cg = rng.uniform(0.1f, 1.0f), cb = rng.uniform(0.1f, 1.0f);
+        int mat = add_material(world, cr, cg, cb, 1.0f);
+        GlobalTransform t;
+        t.translation = v3(cx, cy, cz);
+        // radius baked into the mesh, translation-only transform (as src/main.rs:84-88 does):
+        // prepare_meshinfo's AABB ignores scale, so a scaled unit sphere would be mis-culled
+        spawn(world, add_mesh(world, icosphere_mesh(r, subdivisions)), mat, t);
+    }
+}
+
+void spawn_icosphere_soup(World &world, uint32_t n, uint64_t seed, uint32_t subdivisions) {
+    SplitMix64 rng(seed);
+    for (uint32_t i = 0; i < n; ++i) {
+        float cx = rng.uniform(-50.0f, 50.0f), cy = rng.uniform(-50.0f, 50.0f), cz = rng.uniform(-50.0f, 50.0f);
+        float r = rng.uniform(0.5f, 2.0f);
+        float cr = rng.uniform(0.1f, 1.0f), cg = rng.uniform(0.1f, 1.0f), cb = rng.uniform(0.1f, 1.0f);
+        int mat = add_material(world, cr, cg, cb, 1.0f);
+        GlobalTransform t;
+        t.translation = v3(cx, cy, cz);
+        spawn(world, add_mesh(world, icosphere_mesh(r, subdivisions)), mat, t);
+    }
+}
+
+void frame_synthetic_camera(World &world) {
+    // eye on the bounding sphere of the entity translations at 2.5 radii, looking at the centroid
+    if (world.entities.empty()) return;
+    Vec3 lo = world.entities[0].transform.translation, hi = lo;
+    for (const Entity &e : world.entities) {
+        Vec3 p = e.transform.translation, h = e.aabb.half_extents;
+        lo = v3(std::min(lo.x, p.x - h.x), std::min(lo.y, p.y - h.y), std::min(lo.z, p.z - h.z));
+        hi = v3(std::max(hi.x, p.x + h.x), std::max(hi.y, p.y + h.y), std::max(hi.z, p.z + h.z));
+    }
+    Vec3 c = scl(add(lo, hi), 0.5f);
+    Vec3 d = sub(hi, c);
+    float radius = std::sqrt(dot(d, d));
+    Vec3 dir = normalize(v3(0.35f, 0.45f, 1.0f));
+    world.camera.transform = looking_at(add(c, scl(dir, 2.5f * radius)), c, v3(0, 1, 0));
+}
+
+void rotate_tagged(World &world, float dt) {   // src/main.rs:122-126: ele.rotate_y(1.0 * dt)
+    Quat r = quat_from_axis_angle(v3(0, 1, 0), 1.0f * dt);
+    for (Entity &e : world.entities)
+        if (e.rotate_tag) e.transform.rotation = quat_mul(r, e.transform.rotation);
+}
+
+// ---- L2 pipeline init / L1 launch / plugin ------------------------------------------------------------
+RayTracingPipeline RayTracingPipeline::from_world(World &, int device_ordinal) {   // src/pipeline.rs:25-72
+    RayTracingPipeline p;
+    p.status = rt_create(device_ordinal, &p.ctx);
+    return p;
+}
+void RayTracingPipeline::destroy() {
+    if (ctx) rt_destroy(ctx);
+    ctx = nullptr; status = RT_NOT_READY;
+}
+
+static uint64_t fnv(const void *data, size_t n, uint64_t h) {
+    const unsigned char *p = (const unsigned char *)data;
+    for (size_t i = 0; i < n; ++i) { h ^= p[i]; h *= 0x100000001B3ull; }
+    return h;
+}
+
+int RayTracingPassNode::run(const View &view, World &world, RayTracingPipeline &pipeline,
+                            const rt_render_params *params) {   // src/node.rs:29-79
+    if (!pipeline.ctx || pipeline.status != RT_OK) return RT_NOT_READY;   // pipeline not ready: skip (:52-56)
+    const RayTracingInfo &info = world.ray_tracing_info;
+    // The reference re-creates and re-uploads all five bindings every frame (:42-50).  Here the
+    // arrays go to the GPU (and the BVH is rebuilt) only when their contents change.
+    uint64_t sig = 0xCBF29CE484222325ull;
+    sig = fnv(info.triangles.data(), info.triangles.size() * sizeof(Triangle), sig);
+    sig = fnv(info.meshes.data(), info.meshes.size() * sizeof(MeshInfo), sig);
+    sig = fnv(info.vertices.data(), info.vertices.size() * sizeof(Vertex), sig);
+    sig = fnv(info.materials.data(), info.materials.size() * sizeof(SimpleMaterial), sig);
+    sig ^= info.triangles.size() * 0x9E3779B97F4A7C15ull;
+    if (sig == 0) sig = 1;
+    if (sig != uploaded_signature) {
+        int rc = rt_upload_scene(pipeline.ctx, info.triangles.data(), info.triangles.size(), info.meshes.data(),
+                                 info.meshes.size(), info.vertices.data(), info.vertices.size(),
+                                 info.materials.data(), info.materials.size());
+        if (rc != RT_OK) return rc;
+        uploaded_signature = sig;
+    }
+    uint32_t vp[4] = {view.viewport.x, view.viewport.y, view.viewport.w, view.viewport.h};
+    int rc = rt_set_view(pipeline.ctx, view.world_from_clip, view.world_position, view.width, view.height,
+                         view.has_viewport ? vp : nullptr);                 // bind group 0 + viewport (:58-62,71-76)
+    if (rc != RT_OK) return rc;
+    rt_render_params p;
+    std::memset(&p, 0, sizeof p);
+    if (params) p = *params;
+    p.struct_size = sizeof p;
+    p.frame_count = info.count;
+    return rt_render(pipeline.ctx, &p);                                      // draw(0..3, 0..1) (:77)
+}
+
+void RayTracingPlugin::build(App &app) const {   // src/ray_tracing.rs:29-42
+    app.world.ray_tracing_info = RayTracingInfo();          // insert_resource(RayTracingInfo::default())
+    if (app.has_render_app) {
+        app.extract_registered = true;                      // add_systems(ExtractSchedule, prepare_meshinfo)
+        app.graph_registered = true;                        // add_render_sub_graph + the pass node
+    }
+}
+void RayTracingPlugin::finish(App &app) const {  // src/ray_tracing.rs:44-48
+    if (!app.has_render_app)
+        throw std::runtime_error("RayTracingPlugin::finish: no RenderApp (reference: unwrap() panic, src/ray_tracing.rs:46)");
+    app.pipeline = RayTracingPipeline::from_world(app.world, app.device_ordinal);
+}
+
+int App::update(const rt_render_params *params) {
+    if (extract_registered) prepare_meshinfo(world);
+    if (!graph_registered || !world.camera.ray_tracing_graph) return RT_NOT_READY;   // camera on another graph
+    View v = extract_view(world.camera);
+    return node.run(v, world, pipeline, params);
+}
+
+}  // namespace ray_tracing

@@ -1,0 +1,144 @@
+// ray_tracing.hpp -- host-side mirror of the reference's plugin interface for the hot path,
+// in C++ because the reference is compiled code and no Rust toolchain exists in this image.
+// Same names, argument meaning and error behaviour as the Rust items they stand for:
+//   Triangle / MeshInfo / SimpleMaterial / RayTracingInfo   src/ray_tracing.rs:51-96
+//   prepare_meshinfo                                         src/ray_tracing.rs:98-169
+//   RayTracingPlugin::build / finish, RayTracingGraph        src/ray_tracing.rs:23-49
+//   RayTracingPipeline::from_world                           src/pipeline.rs:19-72
+//   RayTracingPassNode::run                                  src/node.rs:18-80
+// The ECS, asset server and render graph of Bevy are NOT rebuilt: World/App below carry just
+// the data those items read (mesh + material assets, entities with transform and Aabb, one
+// camera), nothing more.
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/rt_amd.h"
+
+namespace ray_tracing {
+
+struct Vec3 { float x = 0, y = 0, z = 0; };
+struct Quat { float x = 0, y = 0, z = 0, w = 1; };
+
+// bevy Mesh, reduced to what prepare_meshinfo reads (positions, normals, indices)
+struct Mesh {
+    std::vector<Vec3> positions;
+    std::vector<Vec3> normals;
+    std::vector<uint32_t> indices;
+    bool has_positions = true, has_normals = true, has_indices = true;
+};
+// bevy render::primitives::Aabb
+struct Aabb { Vec3 center, half_extents; };
+Aabb compute_aabb(const Mesh &m);
+
+struct StandardMaterial { float base_color_linear[4] = {1, 1, 1, 1}; };
+struct GlobalTransform { Vec3 scale{1, 1, 1}; Quat rotation; Vec3 translation; };
+
+struct Entity {
+    int mesh = -1, material = -1;   // handles into World::meshes / World::materials
+    GlobalTransform transform;
+    Aabb aabb;
+    bool rotate_tag = false;        // the `Rotate` marker of src/main.rs:119-126
+};
+
+struct Viewport { uint32_t x = 0, y = 0, w = 0, h = 0; };
+struct Camera {
+    GlobalTransform transform;      // only rotation + translation are used
+    float fov_y = 0.78539816339744830962f;   // PerspectiveProjection default pi/4
+    float near = 0.1f;
+    uint32_t width = 1280, height = 720;
+    bool has_viewport = false;
+    Viewport viewport;
+    bool ray_tracing_graph = true;  // CameraRenderGraph::new(RayTracingGraph), src/main.rs:60
+};
+
+// src/ray_tracing.rs:51-96.  Layouts are the C ABI's (byte-identical to the WGSL bindings).
+using Triangle = rt_triangle;
+using MeshInfo = rt_mesh_info;
+using Vertex = rt_vertex;
+using SimpleMaterial = rt_material;
+struct RayTracingInfo {
+    uint32_t count = 0;
+    std::vector<Triangle> triangles;
+    std::vector<MeshInfo> meshes;
+    std::vector<Vertex> vertices;
+    std::vector<SimpleMaterial> materials;
+};
+
+struct World {
+    std::vector<Mesh> meshes;
+    std::vector<StandardMaterial> materials;
+    std::vector<Entity> entities;     // query order = spawn order (src/ray_tracing.rs:119)
+    Camera camera;
+    RayTracingInfo ray_tracing_info;  // the resource prepare_meshinfo inserts
+    std::string log;                  // "Mesh missing attribute" lines (src/ray_tracing.rs:127)
+};
+
+// src/ray_tracing.rs:98-169.  Throws std::runtime_error where the reference panics
+// (`mesh.indices().unwrap()` on an unindexed mesh, :145; a dangling handle, :120-121).
+void prepare_meshinfo(World &world);
+
+// View uniform pieces the shader reads (bevy_render View: world_from_clip, world_position).
+struct View {
+    float world_from_clip[16];
+    float world_position[3];
+    uint32_t width, height;
+    bool has_viewport;
+    Viewport viewport;
+};
+View extract_view(const Camera &cam);
+
+// camera helpers (glam restatements; un-vendored dependency, parity unpinned)
+Quat quat_from_axis_angle(Vec3 axis, float angle);
+Quat quat_mul(Quat a, Quat b);
+Vec3 quat_rotate(Quat q, Vec3 v);
+GlobalTransform looking_at(Vec3 eye, Vec3 target, Vec3 up);
+
+// mesh generators standing in for bevy's Cuboid / Plane3d / Sphere::mesh() (ico, 5 subdivisions)
+Mesh cuboid_mesh(float sx, float sy, float sz);
+Mesh plane_mesh(float half_x, float half_z);
+Mesh icosphere_mesh(float radius, uint32_t subdivisions);
+
+// scenes
+void spawn_default_scene(World &world);                                  // src/main.rs:51-117
+void spawn_sphere_field(World &world, uint32_t n, uint64_t seed, uint32_t subdivisions);
+void spawn_icosphere_soup(World &world, uint32_t n, uint64_t seed, uint32_t subdivisions);
+void frame_synthetic_camera(World &world);   // eye at 2.5 bounding radii, looking at the centroid
+void rotate_tagged(World &world, float dt);  // `rotate` system, src/main.rs:122-126
+
+// src/pipeline.rs:19-72: one-time GPU-side init (here: the rt_ctx).
+struct RayTracingPipeline {
+    rt_ctx *ctx = nullptr;
+    int status = RT_NOT_READY;
+    static RayTracingPipeline from_world(World &world, int device_ordinal);
+    void destroy();
+};
+
+// src/node.rs:18-80
+struct RayTracingPassNode {
+    uint64_t uploaded_signature = 0;   // scene re-upload only when the arrays change
+    // Returns RT_OK, or RT_NOT_READY when the pipeline is not ready (silent skip, :52-56).
+    int run(const View &view, World &world, RayTracingPipeline &pipeline, const rt_render_params *params);
+};
+
+struct RayTracingGraph {};   // RenderSubGraph label a camera opts into (src/ray_tracing.rs:23-24)
+
+struct App {
+    World world;
+    bool has_render_app = true;
+    bool extract_registered = false, graph_registered = false;
+    RayTracingPipeline pipeline;
+    RayTracingPassNode node;
+    int device_ordinal = 0;
+    // one frame of the RayTracingGraph for the camera: extract, then the pass node
+    int update(const rt_render_params *params);
+};
+
+// src/ray_tracing.rs:26-49
+struct RayTracingPlugin {
+    void build(App &app) const;    // registers the resource, the extract system, the sub-graph
+    void finish(App &app) const;   // init_resource::<RayTracingPipeline>()
+};
+
+}  // namespace ray_tracing

@@ -1,0 +1,12 @@
+"""Import shim: the package directory is named `ray-tracing_amd` (not a valid module name),
+so `import ray_tracing_amd` loads it from there."""
+import importlib.util
+import os
+import sys
+
+_dir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "ray-tracing_amd")
+_spec = importlib.util.spec_from_file_location(
+    "ray_tracing_amd", os.path.join(_dir, "__init__.py"), submodule_search_locations=[_dir])
+_mod = importlib.util.module_from_spec(_spec)
+sys.modules["ray_tracing_amd"] = _mod
+_spec.loader.exec_module(_mod)

@@ -1,0 +1,232 @@
+#!/usr/bin/env python3
+"""bench.py -- Mrays/s of the per-pixel hot path on MI355X (BASELINE.json metric).
+
+Workload at N=1 (BASELINE.json configs[1]): synthetic 10k-sphere field,
+reference-faithful tessellation (ico(5): 7.2 M triangles + ground plane), 1920x1080, one primary
+ray per pixel + one shadow ray per hit.  A step = one frame through rt_render (C ABI).
+N>1: scene replicated, one process per GPU; --mode frames (default) gives every rank its own
+camera on an orbit (weak scaling, no data-path collective); --mode tiles shards ONE frame by
+64x64 screen tiles round-robin over the ranks and combines with one RCCL all_reduce(sum) of the
+zero-initialised radiance buffers (strong scaling).
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` and
+`cpu_baseline` objects.  Never reads /root/reference.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measured copy)
+
+WORKLOADS = {
+    # name: (kind, count, seed, width, height, flags_shadow)
+    "sphere_field_10k_1080p_primary_shadow": ("field", 10000, 0x5EED0002, 1920, 1080),
+    "soup_1m_1080p_primary_shadow": ("soup", 1389, 0x5EED0003, 1920, 1080),
+    "default_640x360": ("default", 0, 0, 640, 360),
+    "sphere_field_200_small": ("field", 200, 0x5EED0002, 640, 360),
+}
+
+
+def build_app(rt, workload, rank=0, world=1):
+    kind, count, seed, W, H = WORKLOADS[workload]
+    app = rt.App()
+    if kind == "field":
+        app.spawn_sphere_field(count, seed, 5)
+        app.camera_frame_scene()
+    elif kind == "soup":
+        app.spawn_icosphere_soup(count, seed, 5)
+        app.camera_frame_scene()
+    else:
+        app.spawn_default_scene()
+    app.camera_set_target(W, H)
+    return app, W, H
+
+
+def orbit_camera(app, rank, world):
+    """Rank r looks at the scene from its own azimuth (frames mode): same eye distance and height."""
+    if world <= 1:
+        return
+    m, p = app.camera_view()
+    # forward = -third rotation column = world_from_clip column 3 (xyz); keep the look-at target
+    fwd = np.array(m[12:15], np.float64)
+    # target = eye + fwd * distance, distance chosen as the eye's distance to the y=centre plane
+    dist = float(np.linalg.norm(p)) if np.linalg.norm(p) > 0 else 1.0
+    target = np.array(p, np.float64) + fwd * dist
+    rel = np.array(p, np.float64) - target
+    ang = 2.0 * math.pi * rank / world
+    c, s = math.cos(ang), math.sin(ang)
+    rel2 = np.array([c * rel[0] + s * rel[2], rel[1], -s * rel[0] + c * rel[2]])
+    app.camera_look_at((target + rel2).astype(np.float32), target.astype(np.float32), (0, 1, 0))
+
+
+def cpu_baseline(orc, scene, view, W, H, flags, target_seconds=15.0):
+    """Time the oracle's reference-shaped brute-force loop on a bounded seeded pixel sample."""
+    threads = max(1, min(16, os.cpu_count() or 1))
+    osc = orc.Scene(scene.triangles, scene.meshes, scene.vertices, scene.materials)
+    rng = np.random.default_rng(0x5EED)
+    perm = rng.permutation(W * H).astype(np.uint32)
+    oflags = orc.FLAG_SHADOW if flags & 1 else 0
+    # calibrate on a small slice, then size the sample for ~target_seconds
+    n0 = min(len(perm), 64 * threads)
+    t0 = time.perf_counter()
+    orc.render_primary(osc, view, oflags, threads=threads, pixel_list=perm[:n0])
+    dt0 = max(time.perf_counter() - t0, 1e-6)
+    cap = max(n0, (W * H) // 100)             # at most the 1 % pixel subset named in BASELINE.md section 3
+    n = int(max(n0, min(cap, n0 * target_seconds / dt0)))
+    t0 = time.perf_counter()
+    rgba, prim, t, rays = orc.render_primary(osc, view, oflags, threads=threads, pixel_list=perm[:n])
+    dt = time.perf_counter() - t0
+    return dict(value=rays / dt / 1e6, unit="Mrays/s", cores=threads, kind="port",
+                sample=f"seeded random {n} of {W * H} pixels ({100.0 * n / (W * H):.2f} %), primary+shadow, "
+                       f"reference-shaped brute-force loop (oracle/rt_oracle.c), {dt:.1f} s"), perm[:n], rgba, prim
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="sphere_field_10k_1080p_primary_shadow", choices=sorted(WORKLOADS))
+    ap.add_argument("--mode", default="frames", choices=["frames", "tiles"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: ray_tracing_amd has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    import ray_tracing_amd as rt
+
+    app, W, H = build_app(rt, args.workload, rank, world)
+    tiles = args.mode == "tiles" and world > 1
+    if world > 1 and not tiles:
+        orbit_camera(app, rank, world)
+    scene = app.prepare_meshinfo()            # P1: scene extraction (host)
+    ctx = rt.Context(local_rank)
+    stream = torch.cuda.current_stream()
+    ctx.set_stream(stream.cuda_stream)        # kernels run on torch's stream: events below see them
+    ctx.upload_scene(scene)                   # upload + BVH build, outside the timed region
+    m, p = app.camera_view()
+    ctx.set_view(m, p, W, H)
+    info = ctx.bvh_info()
+
+    flags = rt.FLAG_SHADOW
+    shard = dict(shard_rank=rank, shard_count=world, tile_size=64) if tiles else {}
+
+    # instrumented launch (same view): counted node visits / triangle tests for the roofline
+    ctx.render(flags=flags | rt.FLAG_COUNTERS, **shard)
+    cnt = ctx.counters()
+    rays_step = cnt.rays_primary + cnt.rays_shadow
+    hits = cnt.rays_shadow
+    alg_bytes = (cnt.node_visits * info.node_bytes + cnt.tri_tests * info.tri_bytes + cnt.mesh_aabb_tests * 32 +
+                 cnt.rays_primary * 24 + hits * 80)
+
+    rad_t = None
+    if tiles:
+        d_rad, _, _ = ctx.device_buffers()
+
+        class _Ptr:   # wrap the library's radiance buffer as a torch tensor (no copy)
+            __cuda_array_interface__ = dict(shape=(H * W * 4,), typestr="<f4", data=(d_rad, False), version=2)
+        rad_t = torch.as_tensor(_Ptr(), device=f"cuda:{local_rank}")
+        frame_t = torch.empty_like(rad_t)   # combined frame; the library's buffer keeps only this rank's tiles
+
+    def step(f):
+        ctx.render(flags=f, **shard)
+        if tiles:
+            frame_t.copy_(rad_t)
+            dist.all_reduce(frame_t, op=dist.ReduceOp.SUM)   # other ranks' tiles are zero here: sum == gather
+
+    for _ in range(args.warmup):
+        step(flags)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(flags | rt.FLAG_TIME_KERNELS)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    kc = ctx.counters()                        # sums the per-launch HIP event pairs
+    kernel_ms = kc.kernel_ms / max(kc.kernel_launches, 1)
+
+    total_rays = float(rays_step)
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+        rr = torch.tensor([total_rays], dtype=torch.float64, device="cuda")
+        dist.all_reduce(rr, op=dist.ReduceOp.SUM)
+        total_rays = float(rr.item())
+
+    if rank == 0:
+        ms_per_step = dt / args.steps * 1e3
+        value = total_rays * args.steps / dt / 1e6
+        achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                tj = json.load(open(tpath))
+                if tj.get("workload") == args.workload:
+                    traffic = tj.get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "Mrays/s", "value": round(value, 2), "unit": "Mrays/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True, "scaling": "strong" if tiles else "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": args.workload, "resolution": f"{W}x{H}", "rays": "primary+shadow, 1 spp",
+                       "triangles": int(info.n_triangles), "bvh_nodes": int(info.n_nodes),
+                       "rays_per_step_rank0": int(rays_step),
+                       "parallelism": ("tiles64-roundrobin+allreduce" if tiles else f"frames-dp{world}")},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                         "kernel": "k_primary<false>", "kernel_ms": round(kernel_ms, 4),
+                         "algorithmic_bytes_per_launch": int(alg_bytes),
+                         "node_visits": int(cnt.node_visits), "tri_tests": int(cnt.tri_tests),
+                         "bytes_per_ray": round(alg_bytes / max(rays_step, 1), 1)},
+        }
+        if not args.no_cpu_baseline:
+            import oracle_py as orc
+            view = orc.make_view(m, p, W, H)
+            cb, pix, rgba_o, prim_o = cpu_baseline(orc, scene, view, W, H, flags, args.cpu_seconds)
+            out["cpu_baseline"] = cb
+            if not tiles:
+                # parity gate on the same sample
+                prim_g = ctx.read_prim_ids().ravel()[pix]
+                rgba_g = ctx.read_radiance().reshape(-1, 4)[pix]
+                d = rgba_g.astype(np.float64) - rgba_o.astype(np.float64)
+                out["parity"] = {"prim_id_agreement": float((prim_g == prim_o).mean()),
+                                 "radiance_rmse": float(np.sqrt(np.mean(d * d))), "pixels": int(len(pix))}
+        print(json.dumps(out), flush=True)
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

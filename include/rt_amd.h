@@ -141,6 +141,14 @@ int rt_get_bvh_info(rt_ctx *ctx, rt_bvh_info *out);
 /* Copy the flattened BVH out (host buffers sized from rt_get_bvh_info). */
 int rt_read_bvh(rt_ctx *ctx, void *nodes, size_t node_bytes_total, void *tris, size_t tri_bytes_total);
 
+/* Host-only BVH build over the same arrays (no GPU touched): lets the builder and the flattened
+ * layout be checked on a machine without a device.  Sizes from *info, then copy, then free. */
+typedef struct rt_host_bvh rt_host_bvh;
+int rt_host_bvh_build(const rt_triangle *triangles, size_t n_triangles, const rt_mesh_info *meshes, size_t n_meshes,
+                      const rt_vertex *vertices, size_t n_vertices, int n_threads, rt_host_bvh **out, rt_bvh_info *info);
+int rt_host_bvh_copy(const rt_host_bvh *bvh, void *nodes, size_t node_bytes_total, void *tris, size_t tri_bytes_total);
+void rt_host_bvh_free(rt_host_bvh *bvh);
+
 const char *rt_last_error(rt_ctx *ctx);   /* ctx may be NULL: last error of rt_create */
 const char *rt_status_string(int status);
 const char *rt_version(void);

@@ -72,7 +72,7 @@ class EntityView(C.Structure):
 RT_SYMBOLS = ["rt_create", "rt_destroy", "rt_set_stream", "rt_upload_scene", "rt_set_view", "rt_render",
               "rt_synchronize", "rt_read_radiance", "rt_read_prim_ids", "rt_read_hit_t", "rt_read_bgra8_srgb",
               "rt_read_accumulation", "rt_device_buffers", "rt_resolve_accumulation", "rt_get_counters",
-              "rt_get_bvh_info", "rt_read_bvh", "rt_last_error", "rt_status_string", "rt_version"]
+              "rt_get_bvh_info", "rt_read_bvh", "rt_host_bvh_build", "rt_host_bvh_copy", "rt_host_bvh_free", "rt_last_error", "rt_status_string", "rt_version"]
 RTH_SYMBOLS = ["rth_app_create", "rth_app_destroy", "rth_app_finish", "rth_app_update", "rth_app_ctx",
                "rth_last_error", "rth_add_mesh", "rth_add_cuboid", "rth_add_plane", "rth_add_icosphere",
                "rth_add_material", "rth_spawn", "rth_set_transform", "rth_set_aabb", "rth_clear_world",
@@ -106,6 +106,8 @@ def lib():
         "rt_resolve_accumulation": (i, [vp, u32]),
         "rt_get_counters": (i, [vp, C.POINTER(Counters)]), "rt_get_bvh_info": (i, [vp, C.POINTER(BvhInfo)]),
         "rt_read_bvh": (i, [vp, vp, sz, vp, sz]),
+        "rt_host_bvh_build": (i, [vp, sz, vp, sz, vp, sz, i, C.POINTER(vp), C.POINTER(BvhInfo)]),
+        "rt_host_bvh_copy": (i, [vp, vp, sz, vp, sz]), "rt_host_bvh_free": (None, [vp]),
         "rt_last_error": (C.c_char_p, [vp]), "rt_status_string": (C.c_char_p, [i]), "rt_version": (C.c_char_p, []),
         "rth_app_create": (vp, []), "rth_app_destroy": (None, [vp]), "rth_app_finish": (i, [vp, i]),
         "rth_app_update": (i, [vp, C.POINTER(RenderParams)]), "rth_app_ctx": (vp, [vp]),
@@ -157,6 +159,20 @@ class Scene:
         self.meshes = np.ascontiguousarray(meshes, dtype=MESH_INFO)
         self.vertices = np.ascontiguousarray(vertices, dtype=VERTEX)
         self.materials = np.ascontiguousarray(materials, dtype=MATERIAL)
+
+
+def host_bvh_build(scene, threads=0):
+    """BVH built on the host only (no GPU): returns (info, nodes, tri_records)."""
+    h, info = C.c_void_p(), BvhInfo()
+    t, m, v = scene.triangles, scene.meshes, scene.vertices
+    rc = lib().rt_host_bvh_build(t.ctypes.data, t.size, m.ctypes.data, m.size, v.ctypes.data, v.size, threads,
+                                 C.byref(h), C.byref(info))
+    if rc != RT_OK:
+        raise RtError(rc, lib().rt_last_error(None).decode())
+    nodes, recs = np.empty(info.n_nodes, dtype=BVH_NODE), np.empty(info.n_triangles, dtype=TRI_RECORD)
+    lib().rt_host_bvh_copy(h, nodes.ctypes.data, nodes.nbytes, recs.ctypes.data, recs.nbytes)
+    lib().rt_host_bvh_free(h)
+    return info, nodes, recs
 
 
 class Context:

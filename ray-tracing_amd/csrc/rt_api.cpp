@@ -213,24 +213,76 @@ int rt_synchronize(rt_ctx *c) {
     return RT_OK;
 }
 
-int rt_upload_scene(rt_ctx *c, const rt_triangle *tris, size_t n_tris, const rt_mesh_info *meshes, size_t n_meshes,
-                    const rt_vertex *verts, size_t n_verts, const rt_material *mats, size_t n_mats) {
-    if (!c) return RT_ERR_ARG;
-    if ((n_tris && !tris) || (n_meshes && !meshes) || (n_verts && !verts) || (n_mats && !mats))
-        return fail(c, RT_ERR_ARG, "rt_upload_scene: NULL array with non-zero count");
+static int validate_scene(rt_ctx *c, const rt_triangle *tris, size_t n_tris, const rt_mesh_info *meshes, size_t n_meshes,
+                          const rt_vertex *verts, size_t n_verts) {
+    if ((n_tris && !tris) || (n_meshes && !meshes) || (n_verts && !verts))
+        return fail(c, RT_ERR_ARG, "scene: NULL array with non-zero count");
     if (n_tris >= (1u << 28) || n_verts > 0xFFFFFFFFull || n_meshes > 0xFFFFFFFFull)
-        return fail(c, RT_ERR_ARG, "rt_upload_scene: scene too large (2^28 triangles max)");
-    // validate before touching the GPU: a kernel must never see an out-of-range index
+        return fail(c, RT_ERR_ARG, "scene: too large (2^28 triangles max)");
     uint64_t loop_items = 0;
     for (size_t m = 0; m < n_meshes; ++m) {
         uint64_t end = (uint64_t)meshes[m].first_tri + meshes[m].tri_count;
-        if (end > n_tris) return fail(c, RT_ERR_SCENE, "rt_upload_scene: mesh triangle range exceeds the triangle array");
+        if (end > n_tris) return fail(c, RT_ERR_SCENE, "scene: mesh triangle range exceeds the triangle array");
         loop_items += meshes[m].tri_count;
     }
-    if (loop_items >= (1u << 28)) return fail(c, RT_ERR_ARG, "rt_upload_scene: too many (mesh, triangle) items");
+    if (loop_items >= (1u << 28)) return fail(c, RT_ERR_ARG, "scene: too many (mesh, triangle) items");
     for (size_t t = 0; t < n_tris; ++t)
         for (int k = 0; k < 3; ++k)
-            if (tris[t].indices[k] >= n_verts) return fail(c, RT_ERR_SCENE, "rt_upload_scene: vertex index out of range");
+            if (tris[t].indices[k] >= n_verts) return fail(c, RT_ERR_SCENE, "scene: vertex index out of range");
+    return RT_OK;
+}
+
+struct rt_host_bvh { RtBvhBuildResult r; };
+
+static void fill_info(rt_bvh_info *info, const RtBvhBuildResult &bvh, size_t n_meshes, size_t n_verts) {
+    info->n_nodes = bvh.nodes.size();
+    info->n_triangles = bvh.recs.size();
+    info->n_meshes = n_meshes;
+    info->n_vertices = n_verts;
+    info->node_bytes = sizeof(RtBvhNode);
+    info->tri_bytes = sizeof(RtTriRecord);
+    info->max_depth = bvh.max_depth;
+    info->max_leaf = bvh.max_leaf;
+    info->build_ms = bvh.build_ms;
+    info->sah_cost = bvh.sah_cost;
+}
+
+int rt_host_bvh_build(const rt_triangle *tris, size_t n_tris, const rt_mesh_info *meshes, size_t n_meshes,
+                      const rt_vertex *verts, size_t n_verts, int n_threads, rt_host_bvh **out, rt_bvh_info *info) {
+    if (!out) return RT_ERR_ARG;
+    *out = nullptr;
+    int rc = validate_scene(nullptr, tris, n_tris, meshes, n_meshes, verts, n_verts);
+    if (rc != RT_OK) return rc;
+    rt_host_bvh *h = new (std::nothrow) rt_host_bvh();
+    if (!h) return RT_ERR_OOM;
+    try {
+        rt_bvh_build(tris, n_tris, meshes, n_meshes, verts, n_verts, n_threads, &h->r);
+    } catch (const std::bad_alloc &) {
+        delete h;
+        return fail(nullptr, RT_ERR_OOM, "rt_host_bvh_build: host allocation failed");
+    }
+    if (info) fill_info(info, h->r, n_meshes, n_verts);
+    *out = h;
+    return RT_OK;
+}
+int rt_host_bvh_copy(const rt_host_bvh *h, void *nodes, size_t nb, void *tris, size_t tb) {
+    if (!h) return RT_ERR_ARG;
+    if (nb != h->r.nodes.size() * sizeof(RtBvhNode) || tb != h->r.recs.size() * sizeof(RtTriRecord)) return RT_ERR_ARG;
+    if (nodes && nb) std::memcpy(nodes, h->r.nodes.data(), nb);
+    if (tris && tb) std::memcpy(tris, h->r.recs.data(), tb);
+    return RT_OK;
+}
+void rt_host_bvh_free(rt_host_bvh *h) { delete h; }
+
+int rt_upload_scene(rt_ctx *c, const rt_triangle *tris, size_t n_tris, const rt_mesh_info *meshes, size_t n_meshes,
+                    const rt_vertex *verts, size_t n_verts, const rt_material *mats, size_t n_mats) {
+    if (!c) return RT_ERR_ARG;
+    if (n_mats && !mats) return fail(c, RT_ERR_ARG, "rt_upload_scene: NULL materials with non-zero count");
+    // validate before touching the GPU: a kernel must never see an out-of-range index
+    {
+        int vrc = validate_scene(c, tris, n_tris, meshes, n_meshes, verts, n_verts);
+        if (vrc != RT_OK) return vrc;
+    }
 
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -265,16 +317,7 @@ int rt_upload_scene(rt_ctx *c, const rt_triangle *tris, size_t n_tris, const rt_
     c->S.n_meshes = (uint32_t)n_meshes;
     c->S.n_verts = (uint32_t)n_verts;
     c->S.n_mats = (uint32_t)n_mats;
-    c->info.n_nodes = bvh.nodes.size();
-    c->info.n_triangles = bvh.recs.size();
-    c->info.n_meshes = n_meshes;
-    c->info.n_vertices = n_verts;
-    c->info.node_bytes = sizeof(RtBvhNode);
-    c->info.tri_bytes = sizeof(RtTriRecord);
-    c->info.max_depth = bvh.max_depth;
-    c->info.max_leaf = bvh.max_leaf;
-    c->info.build_ms = bvh.build_ms;
-    c->info.sah_cost = bvh.sah_cost;
+    fill_info(&c->info, bvh, n_meshes, n_verts);
     c->has_scene = true;
     c->accum_samples = 0;
     c->coverage_sig = 0;

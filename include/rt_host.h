@@ -54,7 +54,8 @@ void rth_rotate_tagged(rth_app *app, float dt);                                 
 
 /* ---- camera ---------------------------------------------------------------------------------- */
 void rth_camera_look_at(rth_app *app, const float eye[3], const float target[3], const float up[3]);
-void rth_camera_frame_scene(rth_app *app);
+void rth_camera_frame_scene(rth_app *app);                 /* eye at 2.5 bounding radii */
+void rth_camera_frame_scene_at(rth_app *app, float radii); /* same, at a chosen distance */
 void rth_camera_set_target(rth_app *app, uint32_t width, uint32_t height, const uint32_t viewport[4] /* or NULL */);
 void rth_camera_set_projection(rth_app *app, float fov_y, float near_plane);
 void rth_camera_set_graph(rth_app *app, int ray_tracing_graph);   /* Tab toggle, src/main.rs:128-147 */

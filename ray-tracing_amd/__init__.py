@@ -25,6 +25,7 @@ FLAG_COUNTERS = 0x0008
 FLAG_PATH_TRACE = 0x0010
 FLAG_ACCUMULATE = 0x0020
 FLAG_TIME_KERNELS = 0x0040
+FLAG_WAVE_TRAVERSAL = 0x0080
 
 MISS_PRIM = 0xFFFFFFFF
 
@@ -77,7 +78,7 @@ RTH_SYMBOLS = ["rth_app_create", "rth_app_destroy", "rth_app_finish", "rth_app_u
                "rth_last_error", "rth_add_mesh", "rth_add_cuboid", "rth_add_plane", "rth_add_icosphere",
                "rth_add_material", "rth_spawn", "rth_set_transform", "rth_set_aabb", "rth_clear_world",
                "rth_spawn_default_scene", "rth_spawn_sphere_field", "rth_spawn_icosphere_soup", "rth_rotate_tagged",
-               "rth_camera_look_at", "rth_camera_frame_scene", "rth_camera_set_target", "rth_camera_set_projection",
+               "rth_camera_look_at", "rth_camera_frame_scene", "rth_camera_frame_scene_at", "rth_camera_set_target", "rth_camera_set_projection",
                "rth_camera_set_graph", "rth_fly_cam_step", "rth_camera_view", "rth_prepare_meshinfo",
                "rth_info_counts", "rth_info_copy", "rth_log", "rth_entity_count", "rth_entity_get"]
 
@@ -119,7 +120,7 @@ def lib():
         "rth_clear_world": (None, [vp]), "rth_spawn_default_scene": (None, [vp]),
         "rth_spawn_sphere_field": (None, [vp, u32, u64, u32]), "rth_spawn_icosphere_soup": (None, [vp, u32, u64, u32]),
         "rth_rotate_tagged": (None, [vp, C.c_float]), "rth_camera_look_at": (None, [vp, fp, fp, fp]),
-        "rth_camera_frame_scene": (None, [vp]), "rth_camera_set_target": (None, [vp, u32, u32, C.POINTER(u32)]),
+        "rth_camera_frame_scene": (None, [vp]), "rth_camera_frame_scene_at": (None, [vp, C.c_float]), "rth_camera_set_target": (None, [vp, u32, u32, C.POINTER(u32)]),
         "rth_camera_set_projection": (None, [vp, C.c_float, C.c_float]), "rth_camera_set_graph": (None, [vp, i]),
         "rth_fly_cam_step": (None, [vp, C.c_float, C.c_float, u32, C.c_float]),
         "rth_camera_view": (None, [vp, fp, fp]), "rth_prepare_meshinfo": (i, [vp]),
@@ -370,8 +371,11 @@ class App:
     def camera_look_at(self, eye, target=(0, 0, 0), up=(0, 1, 0)):
         lib().rth_camera_look_at(self._h, _fp(_f32(eye, 3)), _fp(_f32(target, 3)), _fp(_f32(up, 3)))
 
-    def camera_frame_scene(self):
-        lib().rth_camera_frame_scene(self._h)
+    def camera_frame_scene(self, radii=None):
+        if radii is None:
+            lib().rth_camera_frame_scene(self._h)
+        else:
+            lib().rth_camera_frame_scene_at(self._h, radii)
 
     def camera_set_target(self, width, height, viewport=None):
         vp = (C.c_uint32 * 4)(*viewport) if viewport is not None else None

@@ -105,8 +105,10 @@ void free_frame(rt_ctx *c) {
 template <class T>
 int upload(rt_ctx *c, void *&dst, const T *src, size_t n) {
     free_dev(dst);
-    size_t bytes = (n ? n : 1) * sizeof(T);
+    // +64 B tail: the wave-coherent kernels fetch 48-B records through a 64-B window
+    size_t bytes = (n ? n : 1) * sizeof(T) + 64;
     HIPCHK(c, hipMalloc(&dst, bytes));
+    HIPCHK(c, hipMemsetAsync((char *)dst + bytes - 64 - (n ? 0 : sizeof(T)), 0, 64 + (n ? 0 : sizeof(T)), c->stream));
     if (n) HIPCHK(c, hipMemcpyAsync(dst, src, n * sizeof(T), hipMemcpyHostToDevice, c->stream));
     return RT_OK;
 }

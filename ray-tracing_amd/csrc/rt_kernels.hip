@@ -161,6 +161,114 @@ __device__ __forceinline__ void traverse(const RtSceneDev &S, f3 o, f3 d, uint32
     }
 }
 
+
+// ---- wave-coherent (packet) BVH traversal: one node fetch per WAVE, through the scalar cache ------
+// Primary rays of an 8x8 pixel tile, and their shadow rays toward +Y, walk nearly the same
+// subtrees.  Here the wave walks the tree as one unit: the node index is wave-uniform, the 64-B
+// node is read ONCE per wave (one coalesced request instead of a gather of 64 different lines),
+// every lane tests its own ray against the node's two child boxes straight from SGPR operands, and the wave descends where any lane hits
+// (ballot).  The traversal stack is wave-uniform too (one small LDS column per wave).
+// Per-lane results are identical to traverse<>: the same triangle arithmetic, the same
+// order-independent closest-hit rule (lowest t, then lowest seq), conservative box culls only.
+// Wave-uniform record fetch: lane l reads dword (l & 15) of the record -- ONE coalesced 64-B
+// vector-memory request per wave -- and the dwords are then broadcast to SGPRs with v_readlane.
+// (Scalar-cache s_load was tried first: its miss path serialises and ran 1.4x slower than the
+// per-lane kernel on a 7.2 M-triangle scene; the vector L1 keeps many misses in flight.)
+struct q4 { float x, y, z, w; };
+__device__ __forceinline__ float wave_fetch16(const void *rec) {
+    return reinterpret_cast<const float *>(rec)[threadIdx.x & 15u];
+}
+__device__ __forceinline__ float bcast(float v, int lane) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+#define RT_BCAST4(v, i) q4{bcast(v, 4 * (i)), bcast(v, 4 * (i) + 1), bcast(v, 4 * (i) + 2), bcast(v, 4 * (i) + 3)}
+
+template <bool ANY, bool COUNT>
+__device__ __forceinline__ void traverse_packet(const RtSceneDev &S, f3 o, f3 d, bool alive, uint32_t flags,
+                                                int *wstk, Hit &h, Cnt &c) {
+    h.hit = false; h.t = RT_INF; h.u = 0.0f; h.v = 0.0f; h.seq = 0xFFFFFFFFu; h.tri = 0xFFFFFFFFu; h.mesh = 0;
+    if (S.n_nodes == 0) return;
+    if (__ballot(alive) == 0ull) return;
+    const f3 inv = F3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    const bool lane0 = (threadIdx.x & 63u) == 0u;
+    int sp = 0;
+    int cur = 0;
+    uint32_t last_mesh = 0xFFFFFFFFu;
+    bool last_ok = true;
+    float limit = RT_INF;
+    for (;;) {
+        cur = __builtin_amdgcn_readfirstlane(cur);
+        if (cur >= 0) {
+            float nv = wave_fetch16(S.nodes + cur);
+            q4 q0 = RT_BCAST4(nv, 0), q1 = RT_BCAST4(nv, 1), q2 = RT_BCAST4(nv, 2), q3 = RT_BCAST4(nv, 3);
+            if (COUNT) c.nodes += lane0 ? 1u : 0u;
+            float ax0 = (q0.x - o.x) * inv.x, ax1 = (q0.w - o.x) * inv.x;
+            float ay0 = (q0.y - o.y) * inv.y, ay1 = (q1.x - o.y) * inv.y;
+            float az0 = (q0.z - o.z) * inv.z, az1 = (q1.y - o.z) * inv.z;
+            float bx0 = (q1.z - o.x) * inv.x, bx1 = (q2.y - o.x) * inv.x;
+            float by0 = (q1.w - o.y) * inv.y, by1 = (q2.z - o.y) * inv.y;
+            float bz0 = (q2.x - o.z) * inv.z, bz1 = (q2.w - o.z) * inv.z;
+            float tmin0 = fmaxf(fmaxf(fminf(ax0, ax1), fminf(ay0, ay1)), fminf(az0, az1));
+            float tmax0 = fminf(fminf(fmaxf(ax0, ax1), fmaxf(ay0, ay1)), fmaxf(az0, az1));
+            float tmin1 = fmaxf(fmaxf(fminf(bx0, bx1), fminf(by0, by1)), fminf(bz0, bz1));
+            float tmax1 = fminf(fminf(fmaxf(bx0, bx1), fmaxf(by0, by1)), fmaxf(bz0, bz1));
+            tmax0 *= 1.0000005f; tmax1 *= 1.0000005f;
+            bool h0 = alive && tmin0 <= tmax0 && tmax0 >= 0.0f && tmin0 <= limit;
+            bool h1 = alive && tmin1 <= tmax1 && tmax1 >= 0.0f && tmin1 <= limit;
+            unsigned long long m0 = __ballot(h0), m1 = __ballot(h1);
+            int c0 = __float_as_int(q3.x), c1 = __float_as_int(q3.y);
+            if (m0 && m1) {
+                // near child by vote of the lanes that hit something
+                unsigned long long w1 = __ballot(h1 && (!h0 || tmin1 < tmin0));
+                bool swap = 2 * __builtin_popcountll(w1) > __builtin_popcountll(m0 | m1);
+                int nearc = swap ? c1 : c0, farc = swap ? c0 : c1;
+                if (lane0) wstk[sp] = farc;
+                ++sp;
+                cur = nearc;
+                continue;
+            }
+            if (m0) { cur = c0; continue; }
+            if (m1) { cur = c1; continue; }
+        } else if (cur != RT_CHILD_NONE) {
+            uint32_t code = (uint32_t)(~cur);
+            uint32_t first = code >> 3, n = (code & 7u) + 1u;
+            for (uint32_t k = 0; k < n; ++k) {
+                // 48-B record: dwords 12..15 of the 64-B window belong to the next record (or the
+                // 16-B tail pad the upload adds); they are fetched and ignored
+                float rv = wave_fetch16(S.recs + first + k);
+                q4 r0 = RT_BCAST4(rv, 0), r1 = RT_BCAST4(rv, 1), r2 = RT_BCAST4(rv, 2);
+                if (COUNT) c.tris += lane0 ? 1u : 0u;
+                float dst, u, v;
+                bool ok = ray_tri(o, d, F3(r0.x, r0.y, r0.z), F3(r0.w, r1.x, r1.y), F3(r1.z, r1.w, r2.x), dst, u, v);
+                uint32_t seq = __float_as_uint(r2.w);
+                ok = ok && alive && (dst < h.t || (dst == h.t && seq < h.seq));
+                if (__ballot(ok) == 0ull) continue;
+                uint32_t mesh = __float_as_uint(r2.z);
+                if (!(flags & RT_FLAG_NO_MESH_CULL)) {
+                    if (mesh != last_mesh) {      // wave-uniform: the whole wave looks at one triangle
+                        float mv = wave_fetch16(S.meshes + mesh);   // 48-B MeshInfo, same 64-B window rule
+                        q4 m1v = RT_BCAST4(mv, 1), m2v = RT_BCAST4(mv, 2);
+                        last_ok = ray_aabb_ref(o, inv, F3(m1v.x, m1v.y, m1v.z), F3(m2v.x, m2v.y, m2v.z));
+                        last_mesh = mesh;
+                        if (COUNT) c.meshes += lane0 ? 1u : 0u;
+                    }
+                    ok = ok && last_ok;
+                }
+                if (ok) {
+                    h.hit = true; h.t = dst; h.u = u; h.v = v; h.seq = seq;
+                    h.tri = __float_as_uint(r2.y); h.mesh = mesh;
+                    limit = dst * 1.00001f;
+                    if (ANY) alive = false;       // this lane's shadow ray is answered
+                }
+            }
+            if (ANY && __ballot(alive) == 0ull) return;
+        }
+        if (sp == 0) break;
+        --sp;
+        cur = wstk[sp];
+    }
+}
+
 // ---- A5 reference-shaped closest hit (ray_tracing.wgsl:150-170): meshes, AABB cull, triangles ----
 template <bool ANY, bool COUNT>
 __device__ __forceinline__ void brute_force(const RtSceneDev &S, f3 o, f3 d, uint32_t flags, Hit &h, Cnt &c) {
@@ -215,21 +323,23 @@ __device__ __forceinline__ void finish_hit(const RtSceneDev &S, f3 o, f3 d, cons
 }
 
 // ---- pixel mapping: shard tiles -> 16x16 blocks -> 8x8 waves; XCD-aware block order -----------
-// Blocks b and b+8 share an XCD (and its 4 MiB L2) under round-robin dispatch, so the logical
-// block order gives every XCD one contiguous run of screen tiles: rays that walk the same BVH
-// subtrees hit the same L2.  Speed only, never correctness.
-__device__ __forceinline__ uint32_t xcd_remap(uint32_t b, uint32_t nb) {
-    uint32_t q = nb >> 3, r = nb & 7u, x = b & 7u;
-    uint32_t base = x < r ? x * (q + 1u) : r * (q + 1u) + (x - r) * q;
-    return base + (b >> 3);
-}
-
+// Blocks b and b+8 share an XCD (and its 4 MiB L2) under round-robin dispatch.  All 16 blocks of
+// one 64x64 shard tile are given the same b % 8, so the rays that walk the same BVH subtrees hit
+// the same L2, while consecutive tiles rotate over the 8 XCDs so that cheap regions (sky) and
+// expensive ones (dense geometry) are spread evenly over the chip.  (Giving every XCD one
+// contiguous screen band was measured first: the sky XCDs idled, 2.5 waves/SIMD on average.)
+// Speed only, never correctness: the mapping is a bijection whatever the placement.
 __device__ __forceinline__ bool pixel_of_thread(const RtViewDev &V, const RtShardDev &sh, uint32_t nb,
                                                 uint32_t &px, uint32_t &py) {
-    uint32_t l = xcd_remap(blockIdx.x, nb);
+    (void)nb;
     uint32_t sub = sh.tile / RT_WORK_TILE;
     uint32_t per_tile = sub * sub;
-    uint32_t k = l / per_tile, s = l % per_tile;
+    uint32_t b = blockIdx.x;
+    uint32_t xcd = b & 7u, j = b >> 3;
+    uint32_t k = (j / per_tile) * 8u + xcd;      // owned-tile ordinal of this block
+    uint32_t s = j % per_tile;                   // 16x16 sub-block inside the tile
+    px = 0; py = 0;
+    if (k >= sh.n_owned) return false;
     uint32_t g = sh.rank + k * (sh.count ? sh.count : 1u);
     uint32_t gx = g % sh.tiles_x, gy = g / sh.tiles_x;
     uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u;
@@ -251,48 +361,57 @@ __device__ __forceinline__ void wave_sum(unsigned long long *ctr, uint32_t v) {
 }
 
 // ---- the live path: ray_tracing.wgsl:173-211 (+ shadow ray) ------------------
-template <bool COUNT>
+__device__ __forceinline__ float4 shade_hit(const RtSceneDev &S, f3 normal, uint32_t material) {
+    if (material >= 100u) {                               // debug grey (wgsl:205-207)
+        float g = 0.5f + (float)(material - 100u) / 6.0f;
+        return make_float4(g, g, g, g);
+    }
+    float ndl = dot(normal, F3(0.0f, 1.0f, 0.0f));
+    float4 col = material < S.n_mats ? *reinterpret_cast<const float4 *>(S.mats + material)
+                                     : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    return make_float4(col.x * ndl, col.y * ndl, col.z * ndl, col.w * ndl);   // alpha scaled too (wgsl:208)
+}
+
+// PACKET = wave-coherent traversal (traverse_packet); otherwise per-lane traversal with the LDS
+// stack (or the reference-shaped loop under RT_FLAG_BRUTE_FORCE).
+template <bool COUNT, bool PACKET>
 __global__ __launch_bounds__(RT_BLOCK) void k_primary(RtSceneDev S, RtViewDev V, RtShardDev sh, uint32_t nb,
                                                       uint32_t flags, float4 *__restrict__ rgba,
                                                       uint32_t *__restrict__ prim, float *__restrict__ tout,
                                                       unsigned long long *__restrict__ counters) {
-    __shared__ int s_stack[RT_STACK_LDS * RT_BLOCK];
-    int *stk = s_stack + threadIdx.x;
+    __shared__ int s_stack[PACKET ? 4 * (RT_MAX_DEPTH + 2) : RT_STACK_LDS * RT_BLOCK];
+    int *stk = PACKET ? s_stack + (threadIdx.x >> 6) * (RT_MAX_DEPTH + 2) : s_stack + threadIdx.x;
     uint32_t px, py;
     bool active = pixel_of_thread(V, sh, nb, px, py);
     Cnt c; c.nodes = 0; c.tris = 0; c.meshes = 0;
-    bool shadowed = false, did_shadow = false;
+    f3 o = F3(0.0f, 0.0f, 0.0f), d = F3(0.0f, 0.0f, 1.0f);
+    if (active) ray_gen(V, px, py, o, d);
+    Hit h;
+    if (PACKET) traverse_packet<false, COUNT>(S, o, d, active, flags, stk, h, c);
+    else if (active) trace<false, COUNT>(S, o, d, flags, stk, h, c);
+    else h.hit = false;
+    float4 out = make_float4(0.0f, 0.0f, 0.0f, 0.0f);        // miss: vec4(0) (wgsl:210)
+    bool hit = active && h.hit;
+    f3 point = F3(0.0f, 0.0f, 0.0f), normal = F3(0.0f, 1.0f, 0.0f);
+    if (hit) {
+        uint32_t material;
+        finish_hit(S, o, d, h, point, normal, material);
+        out = shade_hit(S, normal, material);
+    }
+    bool did_shadow = hit && (flags & RT_FLAG_SHADOW);
+    if (flags & RT_FLAG_SHADOW) {
+        f3 so = add(point, scl(normal, 1e-3f));
+        Hit sh_hit;
+        if (PACKET) traverse_packet<true, COUNT>(S, so, F3(0.0f, 1.0f, 0.0f), did_shadow, flags, stk, sh_hit, c);
+        else if (did_shadow) trace<true, COUNT>(S, so, F3(0.0f, 1.0f, 0.0f), flags, stk, sh_hit, c);
+        else sh_hit.hit = false;
+        if (did_shadow && sh_hit.hit) out = make_float4(out.x * 0.25f, out.y * 0.25f, out.z * 0.25f, out.w * 0.25f);
+    }
     if (active) {
-        f3 o, d;
-        ray_gen(V, px, py, o, d);
-        Hit h;
-        trace<false, COUNT>(S, o, d, flags, stk, h, c);
-        float4 out = make_float4(0.0f, 0.0f, 0.0f, 0.0f);   // miss: vec4(0) (wgsl:210)
-        if (h.hit) {
-            f3 point, normal; uint32_t material;
-            finish_hit(S, o, d, h, point, normal, material);
-            if (material >= 100u) {                           // debug grey (wgsl:205-207)
-                float g = 0.5f + (float)(material - 100u) / 6.0f;
-                out = make_float4(g, g, g, g);
-            } else {
-                float ndl = dot(normal, F3(0.0f, 1.0f, 0.0f));
-                float4 col = material < S.n_mats ? *reinterpret_cast<const float4 *>(S.mats + material)
-                                                 : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-                out = make_float4(col.x * ndl, col.y * ndl, col.z * ndl, col.w * ndl);
-            }
-            if (flags & RT_FLAG_SHADOW) {
-                f3 so = add(point, scl(normal, 1e-3f));
-                Hit sh_hit;
-                trace<true, COUNT>(S, so, F3(0.0f, 1.0f, 0.0f), flags, stk, sh_hit, c);
-                did_shadow = true;
-                shadowed = sh_hit.hit;
-                if (shadowed) out = make_float4(out.x * 0.25f, out.y * 0.25f, out.z * 0.25f, out.w * 0.25f);
-            }
-        }
         size_t idx = (size_t)py * V.width + px;
         rgba[idx] = out;
-        prim[idx] = h.hit ? h.tri : 0xFFFFFFFFu;
-        tout[idx] = h.hit ? h.t : 0.0f;
+        prim[idx] = hit ? h.tri : 0xFFFFFFFFu;
+        tout[idx] = hit ? h.t : 0.0f;
     }
     wave_count(counters + RT_CNT_PRIMARY, active);
     wave_count(counters + RT_CNT_SHADOW, did_shadow);
@@ -525,17 +644,22 @@ __global__ void k_fill_u32(uint32_t *p, uint32_t v, size_t n) {
 // ---- launchers --------------------------------------------------------------------------------------
 uint32_t rtk_primary_blocks(const RtShardDev &sh) {
     uint32_t sub = sh.tile / RT_WORK_TILE;
-    return sh.n_owned * sub * sub;
+    return ((sh.n_owned + 7u) / 8u) * 8u * sub * sub;   // tiles rounded up to a multiple of 8 (XCD rotation)
 }
 
 hipError_t rtk_launch_primary(hipStream_t st, const RtSceneDev &S, const RtViewDev &V, const RtShardDev &sh,
                               uint32_t flags, float *rgba, uint32_t *prim, float *t, unsigned long long *counters) {
     uint32_t nb = rtk_primary_blocks(sh);
     if (nb == 0) return hipSuccess;
-    if (flags & RT_FLAG_COUNTERS)
-        hipLaunchKernelGGL(k_primary<true>, dim3(nb), dim3(RT_BLOCK), 0, st, S, V, sh, nb, flags, (float4 *)rgba, prim, t, counters);
-    else
-        hipLaunchKernelGGL(k_primary<false>, dim3(nb), dim3(RT_BLOCK), 0, st, S, V, sh, nb, flags, (float4 *)rgba, prim, t, counters);
+    bool count = (flags & RT_FLAG_COUNTERS) != 0;
+    bool packet = (flags & RT_FLAG_WAVE_TRAVERSAL) && !(flags & RT_FLAG_BRUTE_FORCE);
+#define RT_LAUNCH_PRIMARY(C, P) \
+    hipLaunchKernelGGL((k_primary<C, P>), dim3(nb), dim3(RT_BLOCK), 0, st, S, V, sh, nb, flags, (float4 *)rgba, prim, t, counters)
+    if (count && packet) RT_LAUNCH_PRIMARY(true, true);
+    else if (count) RT_LAUNCH_PRIMARY(true, false);
+    else if (packet) RT_LAUNCH_PRIMARY(false, true);
+    else RT_LAUNCH_PRIMARY(false, false);
+#undef RT_LAUNCH_PRIMARY
     return hipGetLastError();
 }
 

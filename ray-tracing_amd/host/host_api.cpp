@@ -123,6 +123,7 @@ void rth_camera_look_at(rth_app *a, const float eye[3], const float target[3], c
     if (a) a->app.world.camera.transform = looking_at(V3(eye), V3(target), V3(up));
 }
 void rth_camera_frame_scene(rth_app *a) { if (a) frame_synthetic_camera(a->app.world); }
+void rth_camera_frame_scene_at(rth_app *a, float radii) { if (a) frame_synthetic_camera(a->app.world, radii); }
 void rth_camera_set_target(rth_app *a, uint32_t w, uint32_t h, const uint32_t vp[4]) {
     if (!a) return;
     Camera &c = a->app.world.camera;

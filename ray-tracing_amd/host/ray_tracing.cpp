@@ -373,8 +373,8 @@ void spawn_icosphere_soup(World &world, uint32_t n, uint64_t seed, uint32_t subd
     }
 }
 
-void frame_synthetic_camera(World &world) {
-    // eye on the bounding sphere of the entity translations at 2.5 radii, looking at the centroid
+void frame_synthetic_camera(World &world, float radii) {
+    // eye at `radii` bounding-sphere radii from the centroid (2.5), looking at the centroid
     if (world.entities.empty()) return;
     Vec3 lo = world.entities[0].transform.translation, hi = lo;
     for (const Entity &e : world.entities) {
@@ -386,7 +386,7 @@ void frame_synthetic_camera(World &world) {
     Vec3 d = sub(hi, c);
     float radius = std::sqrt(dot(d, d));
     Vec3 dir = normalize(v3(0.35f, 0.45f, 1.0f));
-    world.camera.transform = looking_at(add(c, scl(dir, 2.5f * radius)), c, v3(0, 1, 0));
+    world.camera.transform = looking_at(add(c, scl(dir, radii * radius)), c, v3(0, 1, 0));
 }
 
 void rotate_tagged(World &world, float dt) {   // src/main.rs:122-126: ele.rotate_y(1.0 * dt)

@@ -104,7 +104,7 @@ Mesh icosphere_mesh(float radius, uint32_t subdivisions);
 void spawn_default_scene(World &world);                                  // src/main.rs:51-117
 void spawn_sphere_field(World &world, uint32_t n, uint64_t seed, uint32_t subdivisions);
 void spawn_icosphere_soup(World &world, uint32_t n, uint64_t seed, uint32_t subdivisions);
-void frame_synthetic_camera(World &world);   // eye at 2.5 bounding radii, looking at the centroid
+void frame_synthetic_camera(World &world, float radii = 2.5f);   // eye at `radii` bounding radii, looking at the centroid
 void rotate_tagged(World &world, float dt);  // `rotate` system, src/main.rs:122-126
 
 // src/pipeline.rs:19-72: one-time GPU-side init (here: the rt_ctx).

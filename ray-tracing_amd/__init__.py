@@ -12,7 +12,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librt_amd.so")
+LIB_PATH = os.environ.get("RT_AMD_LIB", os.path.join(_HERE, "librt_amd.so"))   # override: A/B experiments only
 
 # status codes (include/rt_amd.h)
 RT_OK, RT_NOT_READY = 0, 1
@@ -26,6 +26,7 @@ FLAG_PATH_TRACE = 0x0010
 FLAG_ACCUMULATE = 0x0020
 FLAG_TIME_KERNELS = 0x0040
 FLAG_WAVE_TRAVERSAL = 0x0080
+FLAG_PERSISTENT = 0x0100
 
 MISS_PRIM = 0xFFFFFFFF
 

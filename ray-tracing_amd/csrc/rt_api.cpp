@@ -5,6 +5,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -56,6 +57,8 @@ struct rt_ctx {
     unsigned long long *h_cnt = nullptr;   // pinned
     rt_counters counters{};
     uint64_t primary_total = 0;
+
+    RtTune tune{};
 
     // kernel timing
     std::vector<hipEvent_t> ev;            // pairs: start, stop
@@ -172,6 +175,17 @@ int rt_create(int device_ordinal, rt_ctx **out) {
     rt_ctx *c = new (std::nothrow) rt_ctx();
     if (!c) return fail(nullptr, RT_ERR_OOM, "rt_create: host allocation failed");
     c->device = device_ordinal;
+    // persistent-kernel geometry: 6 blocks of 256 threads per CU (24 KiB LDS stack each); tunables
+    // can be overridden for experiments through RT_TUNE_BLOCKS_PER_CU / RT_TUNE_REFILL_MIN
+    {
+        uint32_t per_cu = 6, refill = 16;
+        if (const char *e = std::getenv("RT_TUNE_BLOCKS_PER_CU")) per_cu = (uint32_t)std::atoi(e);
+        if (const char *e = std::getenv("RT_TUNE_REFILL_MIN")) refill = (uint32_t)std::atoi(e);
+        if (per_cu < 1 || per_cu > 16) per_cu = 6;
+        if (refill < 1 || refill > 64) refill = 16;
+        c->tune.persist_blocks = (uint32_t)prop.multiProcessorCount * per_cu;
+        c->tune.refill_min = refill;
+    }
     int rc = RT_OK;
     do {
         if ((e = hipSetDevice(device_ordinal)) != hipSuccess) { rc = fail(nullptr, RT_ERR_HIP, "hipSetDevice", e); break; }
@@ -421,7 +435,7 @@ int rt_render(rt_ctx *c, const rt_render_params *params) {
     uint32_t launches = 0;
     if (!path) {
         if (timed) HIPCHK(c, hipEventRecord(ev0, c->stream));
-        HIPCHK(c, rtk_launch_primary(c->stream, c->S, c->V, sh, P.flags, c->d_rgba, c->d_prim, c->d_t, c->d_cnt));
+        HIPCHK(c, rtk_launch_primary(c->stream, c->S, c->V, sh, P.flags, c->d_rgba, c->d_prim, c->d_t, c->d_cnt, c->tune));
         launches = 1;
         if (timed) HIPCHK(c, hipEventRecord(ev1, c->stream));
     } else {

@@ -12,9 +12,13 @@ uint32_t rtk_primary_blocks(const RtShardDev &sh);
 
 // Live path of ray_tracing.wgsl:173-211 (+ build-defined shadow ray): ray gen, closest hit,
 // shade, outputs.  flags: RT_FLAG_* of rt_amd.h (SHADOW, NO_MESH_CULL, BRUTE_FORCE, COUNTERS).
+struct RtTune {
+    uint32_t persist_blocks;   // grid of the persistent kernels (CUs x resident blocks per CU)
+    uint32_t refill_min;       // idle lanes in a wave that trigger a refill from the work counter
+};
 hipError_t rtk_launch_primary(hipStream_t st, const RtSceneDev &S, const RtViewDev &V, const RtShardDev &sh,
                               uint32_t flags, float *rgba, uint32_t *prim, float *t,
-                              unsigned long long *counters);
+                              unsigned long long *counters, const RtTune &tune);
 
 // Progressive path tracing (loop shape of ray_tracing.wgsl:180-202) as a wavefront:
 // start = ray gen + jitter + first segment; bounce = one further segment for every queued path.

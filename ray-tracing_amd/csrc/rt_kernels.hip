@@ -8,7 +8,15 @@
 #include <hip/hip_runtime.h>
 #include "rt_kernels.h"
 
-#define RT_STACK_LDS 24
+// Per-lane traversal stack: the first RT_STACK_LDS entries live in LDS (stack[level][thread], bank
+// = lane: conflict-free), deeper levels spill to a private array.  16 entries x 256 threads = 16 KiB
+// per block and <= 64 VGPRs admit 8 waves/SIMD; measured +10 % over 24 entries / 6 waves.
+#ifndef RT_STACK_LDS
+#define RT_STACK_LDS 16
+#endif
+#ifndef RT_MIN_WAVES
+#define RT_MIN_WAVES 8
+#endif
 #define RT_STACK_OVF (RT_MAX_DEPTH + 2 - RT_STACK_LDS)
 #define RT_INF __builtin_huge_valf()
 
@@ -375,7 +383,7 @@ __device__ __forceinline__ float4 shade_hit(const RtSceneDev &S, f3 normal, uint
 // PACKET = wave-coherent traversal (traverse_packet); otherwise per-lane traversal with the LDS
 // stack (or the reference-shaped loop under RT_FLAG_BRUTE_FORCE).
 template <bool COUNT, bool PACKET>
-__global__ __launch_bounds__(RT_BLOCK) void k_primary(RtSceneDev S, RtViewDev V, RtShardDev sh, uint32_t nb,
+__global__ __launch_bounds__(RT_BLOCK, RT_MIN_WAVES) void k_primary(RtSceneDev S, RtViewDev V, RtShardDev sh, uint32_t nb,
                                                       uint32_t flags, float4 *__restrict__ rgba,
                                                       uint32_t *__restrict__ prim, float *__restrict__ tout,
                                                       unsigned long long *__restrict__ counters) {
@@ -415,6 +423,215 @@ __global__ __launch_bounds__(RT_BLOCK) void k_primary(RtSceneDev S, RtViewDev V,
     }
     wave_count(counters + RT_CNT_PRIMARY, active);
     wave_count(counters + RT_CNT_SHADOW, did_shadow);
+    if (COUNT) {
+        wave_sum(counters + RT_CNT_NODES, c.nodes);
+        wave_sum(counters + RT_CNT_TRIS, c.tris);
+        wave_sum(counters + RT_CNT_MESH, c.meshes);
+    }
+}
+
+
+// ---- persistent primary(+shadow) kernel with dynamic ray fetch ---------------------------------------
+// Measured on the per-pixel-per-thread kernel above: only ~31 % of the lanes are active in an
+// average VALU instruction -- a wave runs until its LONGEST ray is done, and the lanes whose
+// primary ray missed idle through the whole shadow phase.  Here waves are persistent: a lane
+// whose ray has finished (primary AND shadow) becomes idle, and as soon as `refill_min` lanes of
+// a wave are idle they take the next pixels from one global work counter (one atomic per wave
+// refill).  Work is handed out in 8x8-tile order, so the rays a wave holds stay coherent.
+// Per-pixel results do not depend on the schedule: same arithmetic, same closest-hit rule.
+// Per-lane state is kept small (occupancy): the best hit is (t, seq, record index); u, v and the
+// mesh are recomputed from the record when the ray ends (same inputs, same bits).
+#define RT_DONE ((int)0x80000001)
+struct LaneRay {
+    f3 o, d, inv;
+    float t;              // best hit distance so far (inf: none)
+    uint32_t seq, rec;    // its loop-order position and its record index
+    int cur, sp;
+};
+
+__device__ __forceinline__ void lr_start(const RtSceneDev &S, LaneRay &r, f3 o, f3 d) {
+    r.o = o; r.d = d;
+    r.inv = F3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    r.t = RT_INF; r.seq = 0xFFFFFFFFu; r.rec = 0xFFFFFFFFu;
+    r.cur = S.n_nodes ? 0 : RT_DONE;
+    r.sp = 0;
+}
+__device__ __forceinline__ int lr_pop(LaneRay &r, const int *stk, const int *ovf) {
+    if (r.sp == 0) return RT_DONE;
+    --r.sp;
+    return r.sp < RT_STACK_LDS ? stk[r.sp * RT_BLOCK] : ovf[r.sp - RT_STACK_LDS];
+}
+
+// Advance one ray: descend inner nodes until a leaf (or the end), then test that leaf.
+// while-while shape: lanes that reached a leaf wait for the wave's node loop, then all leaves of
+// the wave are processed together.  On return r.cur == RT_DONE iff the ray is finished.
+template <bool COUNT>
+__device__ __forceinline__ void lr_advance(const RtSceneDev &S, uint32_t flags, LaneRay &r, bool any, bool active,
+                                           int *stk, int *ovf, Cnt &c) {
+    const float limit = r.t * 1.00001f;   // relaxed bound: near-ties are still visited, seq decides
+    while (active && r.cur >= 0) {
+        const float4 *p = reinterpret_cast<const float4 *>(S.nodes + r.cur);
+        float4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3];
+        if (COUNT) c.nodes++;
+        const f3 o = r.o, inv = r.inv;
+        float ax0 = (q0.x - o.x) * inv.x, ax1 = (q0.w - o.x) * inv.x;
+        float ay0 = (q0.y - o.y) * inv.y, ay1 = (q1.x - o.y) * inv.y;
+        float az0 = (q0.z - o.z) * inv.z, az1 = (q1.y - o.z) * inv.z;
+        float bx0 = (q1.z - o.x) * inv.x, bx1 = (q2.y - o.x) * inv.x;
+        float by0 = (q1.w - o.y) * inv.y, by1 = (q2.z - o.y) * inv.y;
+        float bz0 = (q2.x - o.z) * inv.z, bz1 = (q2.w - o.z) * inv.z;
+        float tmin0 = fmaxf(fmaxf(fminf(ax0, ax1), fminf(ay0, ay1)), fminf(az0, az1));
+        float tmax0 = fminf(fminf(fmaxf(ax0, ax1), fmaxf(ay0, ay1)), fmaxf(az0, az1));
+        float tmin1 = fmaxf(fmaxf(fminf(bx0, bx1), fminf(by0, by1)), fminf(bz0, bz1));
+        float tmax1 = fminf(fminf(fmaxf(bx0, bx1), fmaxf(by0, by1)), fmaxf(bz0, bz1));
+        tmax0 *= 1.0000005f; tmax1 *= 1.0000005f;
+        bool h0 = tmin0 <= tmax0 && tmax0 >= 0.0f && tmin0 <= limit;
+        bool h1 = tmin1 <= tmax1 && tmax1 >= 0.0f && tmin1 <= limit;
+        int c0 = __float_as_int(q3.x), c1 = __float_as_int(q3.y);
+        if (h0 && h1) {
+            bool swap = tmin1 < tmin0;
+            int farc = swap ? c0 : c1;
+            if (r.sp < RT_STACK_LDS) stk[r.sp * RT_BLOCK] = farc;
+            else if (r.sp - RT_STACK_LDS < RT_STACK_OVF) ovf[r.sp - RT_STACK_LDS] = farc;
+            ++r.sp;
+            r.cur = swap ? c1 : c0;
+        } else if (h0) r.cur = c0;
+        else if (h1) r.cur = c1;
+        else r.cur = lr_pop(r, stk, ovf);
+    }
+    if (active && r.cur != RT_DONE) {
+        if (r.cur != RT_CHILD_NONE) {
+            uint32_t code = (uint32_t)(~r.cur);
+            uint32_t first = code >> 3, n = (code & 7u) + 1u;
+            for (uint32_t k = 0; k < n; ++k) {
+                const float4 *t = reinterpret_cast<const float4 *>(S.recs + first + k);
+                float4 r0 = t[0], r1 = t[1], r2 = t[2];
+                if (COUNT) c.tris++;
+                float dst, u, v;
+                bool ok = ray_tri(r.o, r.d, F3(r0.x, r0.y, r0.z), F3(r0.w, r1.x, r1.y), F3(r1.z, r1.w, r2.x), dst, u, v);
+                uint32_t seq = __float_as_uint(r2.w);
+                ok = ok && (dst < r.t || (dst == r.t && seq < r.seq));
+                if (ok && !(flags & RT_FLAG_NO_MESH_CULL)) {   // per-mesh AABB cull of wgsl:155
+                    const float4 *mp = reinterpret_cast<const float4 *>(S.meshes + __float_as_uint(r2.z));
+                    float4 m1 = mp[1], m2 = mp[2];
+                    ok = ray_aabb_ref(r.o, r.inv, F3(m1.x, m1.y, m1.z), F3(m2.x, m2.y, m2.z));
+                    if (COUNT) c.meshes++;
+                }
+                if (ok) {
+                    r.t = dst; r.seq = seq; r.rec = first + k;
+                    if (any) { r.cur = RT_DONE; return; }
+                }
+            }
+        }
+        r.cur = lr_pop(r, stk, ovf);
+    }
+}
+
+// point, interpolated normal (ray_tracing.wgsl:137-138) and material of the ray's best hit
+__device__ __forceinline__ void lr_finish(const RtSceneDev &S, const LaneRay &r, f3 &point, f3 &normal,
+                                          uint32_t &material, uint32_t &tri) {
+    const float4 *t = reinterpret_cast<const float4 *>(S.recs + r.rec);
+    float4 r0 = t[0], r1 = t[1], r2 = t[2];
+    float dst, u, v;
+    (void)ray_tri(r.o, r.d, F3(r0.x, r0.y, r0.z), F3(r0.w, r1.x, r1.y), F3(r1.z, r1.w, r2.x), dst, u, v);
+    Hit h;
+    h.hit = true; h.t = dst; h.u = u; h.v = v; h.seq = r.seq;
+    h.tri = __float_as_uint(r2.y); h.mesh = __float_as_uint(r2.z);
+    tri = h.tri;
+    finish_hit(S, r.o, r.d, h, point, normal, material);
+}
+
+// work index -> pixel: 64 consecutive indices = one 8x8 tile; tiles row-major inside a shard tile
+__device__ __forceinline__ bool pixel_of_index(const RtViewDev &V, const RtShardDev &sh, uint32_t i, uint32_t &px,
+                                               uint32_t &py) {
+    uint32_t sub8 = sh.tile >> 3;
+    uint32_t per_tile = sub8 * sub8;
+    uint32_t t8 = i >> 6, w = i & 63u;
+    uint32_t k = t8 / per_tile, s = t8 % per_tile;
+    uint32_t g = sh.rank + k * (sh.count ? sh.count : 1u);
+    uint32_t gx = g % sh.tiles_x, gy = g / sh.tiles_x;
+    uint32_t x = gx * sh.tile + (s % sub8) * 8u + (w & 7u);
+    uint32_t y = gy * sh.tile + (s / sub8) * 8u + (w >> 3);
+    px = V.vx + x; py = V.vy + y;
+    return x < V.vw && y < V.vh;
+}
+
+#ifndef RT_PERSIST_MIN_WAVES
+#define RT_PERSIST_MIN_WAVES 6
+#endif
+template <bool COUNT>
+__global__ __launch_bounds__(RT_BLOCK, RT_PERSIST_MIN_WAVES) void k_primary_persist(
+    RtSceneDev S, RtViewDev V, RtShardDev sh, uint32_t total, uint32_t flags, uint32_t refill_min,
+    float4 *__restrict__ rgba, uint32_t *__restrict__ prim, float *__restrict__ tout,
+    unsigned long long *__restrict__ counters) {
+    __shared__ int s_stack[RT_STACK_LDS * RT_BLOCK];
+    int *stk = s_stack + threadIdx.x;
+    int ovf[RT_STACK_OVF];
+    const uint32_t lane = threadIdx.x & 63u;
+    Cnt c; c.nodes = 0; c.tris = 0; c.meshes = 0;
+    uint32_t n_primary = 0, n_shadow = 0;
+    int state = 0;                 // 0 idle, 1 primary ray, 2 shadow ray
+    bool exhausted = false;        // wave-uniform: the work counter has run past `total`
+    LaneRay r;
+    lr_start(S, r, F3(0.0f, 0.0f, 0.0f), F3(0.0f, 0.0f, 1.0f));
+    r.cur = RT_DONE;
+    uint32_t idx = 0;
+    for (;;) {
+        unsigned long long idle = __ballot(state == 0);
+        uint32_t n_idle = (uint32_t)__builtin_popcountll(idle);
+        if (!exhausted && (n_idle >= refill_min || n_idle == 64u)) {
+            uint32_t base = 0;
+            int leader = __builtin_ctzll(idle);
+            if ((int)lane == leader) base = (uint32_t)atomicAdd(counters + RT_CNT_WORK, (unsigned long long)n_idle);
+            base = __shfl(base, leader);
+            if (state == 0) {
+                uint32_t my = base + (uint32_t)__builtin_popcountll(idle & ((1ull << lane) - 1ull));
+                uint32_t px, py;
+                if (my < total && pixel_of_index(V, sh, my, px, py)) {
+                    f3 o, d;
+                    ray_gen(V, px, py, o, d);
+                    lr_start(S, r, o, d);
+                    idx = py * V.width + px;
+                    state = 1;
+                    ++n_primary;
+                }
+            }
+            exhausted = base + n_idle >= total;
+        }
+        if (__ballot(state != 0) == 0ull) {
+            if (exhausted) break;
+            continue;
+        }
+        lr_advance<COUNT>(S, flags, r, state == 2, state != 0, stk, ovf, c);
+        if (state != 0 && r.cur == RT_DONE) {
+            if (state == 1) {
+                float4 out = make_float4(0.0f, 0.0f, 0.0f, 0.0f);      // miss: vec4(0) (wgsl:210)
+                uint32_t out_prim = 0xFFFFFFFFu; float out_t = 0.0f;
+                state = 0;
+                if (r.rec != 0xFFFFFFFFu) {
+                    f3 point, normal; uint32_t material;
+                    lr_finish(S, r, point, normal, material, out_prim);
+                    out = shade_hit(S, normal, material);
+                    out_t = r.t;
+                    if (flags & RT_FLAG_SHADOW) {
+                        lr_start(S, r, add(point, scl(normal, 1e-3f)), F3(0.0f, 1.0f, 0.0f));
+                        state = 2;
+                        ++n_shadow;
+                    }
+                }
+                // the unshadowed value is stored now; an occluded shadow ray scales it in place later
+                rgba[idx] = out; prim[idx] = out_prim; tout[idx] = out_t;
+            } else {
+                if (r.rec != 0xFFFFFFFFu) {
+                    float4 out = rgba[idx];
+                    rgba[idx] = make_float4(out.x * 0.25f, out.y * 0.25f, out.z * 0.25f, out.w * 0.25f);
+                }
+                state = 0;
+            }
+        }
+    }
+    wave_sum(counters + RT_CNT_PRIMARY, n_primary);
+    wave_sum(counters + RT_CNT_SHADOW, n_shadow);
     if (COUNT) {
         wave_sum(counters + RT_CNT_NODES, c.nodes);
         wave_sum(counters + RT_CNT_TRIS, c.tris);
@@ -648,11 +865,25 @@ uint32_t rtk_primary_blocks(const RtShardDev &sh) {
 }
 
 hipError_t rtk_launch_primary(hipStream_t st, const RtSceneDev &S, const RtViewDev &V, const RtShardDev &sh,
-                              uint32_t flags, float *rgba, uint32_t *prim, float *t, unsigned long long *counters) {
+                              uint32_t flags, float *rgba, uint32_t *prim, float *t, unsigned long long *counters,
+                              const RtTune &tune) {
     uint32_t nb = rtk_primary_blocks(sh);
     if (nb == 0) return hipSuccess;
     bool count = (flags & RT_FLAG_COUNTERS) != 0;
     bool packet = (flags & RT_FLAG_WAVE_TRAVERSAL) && !(flags & RT_FLAG_BRUTE_FORCE);
+    if (!packet && (flags & RT_FLAG_PERSISTENT) && !(flags & RT_FLAG_BRUTE_FORCE)) {
+        // persistent kernel: a grid that fills the chip once; blocks that start late find the work
+        // counter exhausted and exit, so no residency assumption is made
+        uint32_t total = sh.n_owned * sh.tile * sh.tile;
+        uint32_t need = (total + RT_BLOCK - 1) / RT_BLOCK;
+        uint32_t grid = tune.persist_blocks < need ? tune.persist_blocks : need;
+        if (grid == 0) return hipSuccess;
+        if (count)
+            hipLaunchKernelGGL((k_primary_persist<true>), dim3(grid), dim3(RT_BLOCK), 0, st, S, V, sh, total, flags, tune.refill_min, (float4 *)rgba, prim, t, counters);
+        else
+            hipLaunchKernelGGL((k_primary_persist<false>), dim3(grid), dim3(RT_BLOCK), 0, st, S, V, sh, total, flags, tune.refill_min, (float4 *)rgba, prim, t, counters);
+        return hipGetLastError();
+    }
 #define RT_LAUNCH_PRIMARY(C, P) \
     hipLaunchKernelGGL((k_primary<C, P>), dim3(nb), dim3(RT_BLOCK), 0, st, S, V, sh, nb, flags, (float4 *)rgba, prim, t, counters)
     if (count && packet) RT_LAUNCH_PRIMARY(true, true);

@@ -133,6 +133,8 @@ typedef struct {
     double   kernel_ms;          /* device time of the last rt_render's kernels (TIME_KERNELS) */
     uint32_t kernel_launches;
     uint32_t _pad;
+    uint64_t wave_node_iters;    /* wave-level trips of the node loop / of the triangle loop */
+    uint64_t wave_tri_iters;     /*   (RT_FLAG_COUNTERS, per-lane kernels): lane utilisation */
 } rt_counters;
 int rt_get_counters(rt_ctx *ctx, rt_counters *out);
 

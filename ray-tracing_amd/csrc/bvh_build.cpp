@@ -6,6 +6,7 @@
 #include <atomic>
 #include <chrono>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <thread>
@@ -24,7 +25,9 @@ struct TmpNode {
 };
 
 constexpr int kBins = 16;
-constexpr float kCostNode = 1.0f, kCostTri = 1.0f;
+// SAH cost model; env overrides are experiment hooks (RT_TUNE_COST_TRI, RT_TUNE_MAX_LEAF)
+float kCostNode = 1.0f, kCostTri = 1.0f;
+uint32_t kMaxLeaf = RT_MAX_LEAF;
 constexpr size_t kSpawnMin = 1u << 15;
 
 inline float half_area(const float *lo, const float *hi) {
@@ -69,7 +72,7 @@ struct Builder {
 
         // depth guard: the inner nodes below this one may use at most `room` more levels
         uint32_t room = RT_MAX_DEPTH - 1 - depth;   // levels available for children inner nodes
-        size_t leaves_needed = (n + RT_MAX_LEAF - 1) / RT_MAX_LEAF;
+        size_t leaves_needed = (n + kMaxLeaf - 1) / kMaxLeaf;
         uint32_t need = 0;
         while (((size_t)1 << need) < leaves_needed) ++need;
         bool force_median = need + 1 >= room;           // a balanced split still fits; SAH might not
@@ -115,7 +118,7 @@ struct Builder {
         if (best_axis >= 0) {
             float split_cost = kCostNode + kCostTri * best_cost / (parent_area > 0.0f ? parent_area : 1.0f);
             float leaf_cost = kCostTri * (float)n;
-            if (n <= RT_MAX_LEAF && leaf_cost <= split_cost) { make_leaf(); return; }
+            if (n <= kMaxLeaf && leaf_cost <= split_cost) { make_leaf(); return; }
             float ext = chi[best_axis] - clo[best_axis];
             float scale = (float)kBins / ext;
             float c0 = clo[best_axis];
@@ -129,7 +132,7 @@ struct Builder {
         }
         if (mid == b || mid == e) {
             // no usable SAH split (coincident centroids, or the depth guard): object median
-            if (n <= RT_MAX_LEAF) { make_leaf(); return; }
+            if (n <= kMaxLeaf) { make_leaf(); return; }
             int ax = 0;
             float ex = chi[0] - clo[0];
             for (int k = 1; k < 3; ++k) if (chi[k] - clo[k] > ex) { ex = chi[k] - clo[k]; ax = k; }
@@ -166,6 +169,8 @@ void rt_bvh_build(const rt_triangle *tris, size_t n_tris, const rt_mesh_info *me
     out->nodes.clear(); out->recs.clear();
     out->max_depth = 0; out->max_leaf = 0; out->sah_cost = 0.0; out->dropped = 0;
 
+    if (const char *e = std::getenv("RT_TUNE_COST_TRI")) kCostTri = (float)std::atof(e);
+    if (const char *e = std::getenv("RT_TUNE_MAX_LEAF")) { int v = std::atoi(e); if (v >= 1 && v <= 8) kMaxLeaf = (uint32_t)v; }
     Builder B;
     size_t total = 0;
     for (size_t m = 0; m < n_meshes; ++m) total += meshes[m].tri_count;

@@ -79,7 +79,7 @@ struct Hit {
     bool hit;
 };
 
-struct Cnt { uint32_t nodes, tris, meshes; };
+struct Cnt { uint32_t nodes, tris, meshes, wnodes, wtris; };   // w*: wave-level loop trips (first active lane counts)
 
 // ---- BVH traversal (build-side design; reference src/bvh.rs:1 is empty) ----------------------
 // Closest hit with the reference's tie rule restated order-independently: among equal t the
@@ -102,7 +102,7 @@ __device__ __forceinline__ void traverse(const RtSceneDev &S, f3 o, f3 d, uint32
         if (cur >= 0) {
             const float4 *p = reinterpret_cast<const float4 *>(S.nodes + cur);
             float4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3];
-            if (COUNT) c.nodes++;
+            if (COUNT) { c.nodes++; if ((threadIdx.x & 63u) == (uint32_t)__builtin_ctzll(__ballot(true))) c.wnodes++; }
             // slabs of both children; (plane - o) * inv keeps inf/NaN handling conservative
             float ax0 = (q0.x - o.x) * inv.x, ax1 = (q0.w - o.x) * inv.x;
             float ay0 = (q0.y - o.y) * inv.y, ay1 = (q1.x - o.y) * inv.y;
@@ -135,7 +135,7 @@ __device__ __forceinline__ void traverse(const RtSceneDev &S, f3 o, f3 d, uint32
             for (uint32_t k = 0; k < n; ++k) {
                 const float4 *r = reinterpret_cast<const float4 *>(S.recs + first + k);
                 float4 r0 = r[0], r1 = r[1], r2 = r[2];
-                if (COUNT) c.tris++;
+                if (COUNT) { c.tris++; if ((threadIdx.x & 63u) == (uint32_t)__builtin_ctzll(__ballot(true))) c.wtris++; }
                 float dst, u, v;
                 bool ok = ray_tri(o, d, F3(r0.x, r0.y, r0.z), F3(r0.w, r1.x, r1.y), F3(r1.z, r1.w, r2.x), dst, u, v);
                 uint32_t seq = __float_as_uint(r2.w);
@@ -391,7 +391,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_MIN_WAVES) void k_primary(RtSceneDev S
     int *stk = PACKET ? s_stack + (threadIdx.x >> 6) * (RT_MAX_DEPTH + 2) : s_stack + threadIdx.x;
     uint32_t px, py;
     bool active = pixel_of_thread(V, sh, nb, px, py);
-    Cnt c; c.nodes = 0; c.tris = 0; c.meshes = 0;
+    Cnt c; c.nodes = 0; c.tris = 0; c.meshes = 0; c.wnodes = 0; c.wtris = 0;
     f3 o = F3(0.0f, 0.0f, 0.0f), d = F3(0.0f, 0.0f, 1.0f);
     if (active) ray_gen(V, px, py, o, d);
     Hit h;
@@ -427,6 +427,8 @@ __global__ __launch_bounds__(RT_BLOCK, RT_MIN_WAVES) void k_primary(RtSceneDev S
         wave_sum(counters + RT_CNT_NODES, c.nodes);
         wave_sum(counters + RT_CNT_TRIS, c.tris);
         wave_sum(counters + RT_CNT_MESH, c.meshes);
+        wave_sum(counters + RT_CNT_WNODE, c.wnodes);
+        wave_sum(counters + RT_CNT_WTRI, c.wtris);
     }
 }
 
@@ -568,7 +570,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_PERSIST_MIN_WAVES) void k_primary_pers
     int *stk = s_stack + threadIdx.x;
     int ovf[RT_STACK_OVF];
     const uint32_t lane = threadIdx.x & 63u;
-    Cnt c; c.nodes = 0; c.tris = 0; c.meshes = 0;
+    Cnt c; c.nodes = 0; c.tris = 0; c.meshes = 0; c.wnodes = 0; c.wtris = 0;
     uint32_t n_primary = 0, n_shadow = 0;
     int state = 0;                 // 0 idle, 1 primary ray, 2 shadow ray
     bool exhausted = false;        // wave-uniform: the work counter has run past `total`
@@ -754,7 +756,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_path_start(RtSceneDev S, RtViewDev
     int *stk = s_stack + threadIdx.x;
     uint32_t px, py;
     bool active = pixel_of_thread(V, sh, nb, px, py);
-    Cnt c; c.nodes = 0; c.tris = 0; c.meshes = 0;
+    Cnt c; c.nodes = 0; c.tris = 0; c.meshes = 0; c.wnodes = 0; c.wtris = 0;
     bool alive = false;
     f3 o, d, col; uint32_t rng = 0, pixel = 0;
     if (active) {
@@ -795,7 +797,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_path_bounce(RtSceneDev S, uint32_t
     uint32_t i = blockIdx.x * RT_BLOCK + threadIdx.x;
     if (blockIdx.x * RT_BLOCK >= n) return;            // whole block past the queue end
     bool active = i < n;
-    Cnt c; c.nodes = 0; c.tris = 0; c.meshes = 0;
+    Cnt c; c.nodes = 0; c.tris = 0; c.meshes = 0; c.wnodes = 0; c.wtris = 0;
     bool alive = false;
     f3 o, d, col; uint32_t rng = 0, pixel = 0;
     if (active) {

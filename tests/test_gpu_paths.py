@@ -1,0 +1,255 @@
+"""GPU parity (through the C ABI) of the wider hot-path rows: path tracing + accumulation (A2, A7, A8),
+viewport and tile sharding (L1), presentation (f2), the plugin lifecycle (L1/L2/P1), edge cases, golden
+fixtures, and size-independent properties at the bench's full size."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle_py as orc
+import ray_tracing_amd as rt
+from helpers import bitwise_equal, default_app, field_app, gpu_render, oracle_scene, oracle_view, parity, soup_app
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _golden(name):
+    g = np.load(os.path.join(HERE, "golden", name + ".npz"))
+    scene = rt.Scene(g["triangles"], g["meshes"], g["vertices"], g["materials"])
+    W, H = (int(x) for x in g["size"])
+    return g, scene, W, H
+
+
+@pytest.mark.parametrize("name", ["default_64x36_shadow", "spheres8_48x32"])
+@pytest.mark.parametrize("extra", [0, rt.FLAG_WAVE_TRAVERSAL, rt.FLAG_PERSISTENT, rt.FLAG_BRUTE_FORCE])
+def test_golden_fixtures(name, extra):
+    g, scene, W, H = _golden(name)
+    with rt.Context(0) as ctx:
+        ctx.upload_scene(scene)
+        ctx.set_view(g["world_from_clip"], g["world_position"], W, H)
+        flags = (rt.FLAG_SHADOW if int(g["flags"]) & orc.FLAG_SHADOW else 0) | extra
+        assert ctx.render(flags=flags) == rt.RT_OK
+        assert bitwise_equal(ctx.read_prim_ids(), g["prim"]) and bitwise_equal(ctx.read_hit_t(), g["t"])
+        assert bitwise_equal(ctx.read_radiance(), g["rgba"])
+        c = ctx.counters()
+        assert c.rays_primary + c.rays_shadow == int(g["rays"])
+        if "path_accum" in g and not extra:
+            spp = int(g["path_spp"])
+            assert ctx.render(flags=rt.FLAG_PATH_TRACE, spp=spp, max_segments=4, seed=int(g["path_seed"])) == rt.RT_OK
+            assert bitwise_equal(ctx.read_accumulation(), g["path_accum"])
+            c = ctx.counters()
+            assert c.rays_primary + c.rays_bounce == int(g["path_segments"])
+
+
+@pytest.mark.parametrize("segments", [1, 4, 8])
+def test_path_tracing_matches_the_oracle(segments):
+    app = default_app(96, 54)
+    scene = app.prepare_meshinfo()
+    osc, view = oracle_scene(scene), oracle_view(app)
+    acc_o, segs_o = orc.render_path(osc, view, 3, segments, seed=21, stream=2)
+    with rt.Context(0) as ctx:
+        ctx.upload_scene(scene)
+        m, p = app.camera_view()
+        ctx.set_view(m, p, 96, 54)
+        assert ctx.render(flags=rt.FLAG_PATH_TRACE | rt.FLAG_COUNTERS, spp=3, max_segments=segments, seed=21, stream_id=2) == rt.RT_OK
+        acc_g, rad_g = ctx.read_accumulation(), ctx.read_radiance()
+        c = ctx.counters()
+        rad_o = orc.resolve(acc_o, 3)
+        rmse = float(np.sqrt(np.mean((rad_g.astype(np.float64) - rad_o.astype(np.float64)) ** 2)))
+        assert rmse <= 1e-3, rmse                                    # the stated tolerance
+        assert bitwise_equal(acc_g, acc_o) and bitwise_equal(rad_g, rad_o)   # and in fact bit-exact (integer RNG, det. log/cos)
+        assert c.rays_primary == 96 * 54 * 3 and c.rays_primary + c.rays_bounce == segs_o
+        assert c.node_visits > 0
+
+
+def test_progressive_accumulation_and_reset_on_camera_move():
+    app = default_app(64, 36)
+    scene = app.prepare_meshinfo()
+    osc, view = oracle_scene(scene), oracle_view(app)
+    with rt.Context(0) as ctx:
+        ctx.upload_scene(scene)
+        m, p = app.camera_view()
+        ctx.set_view(m, p, 64, 36)
+        # 2 + 3 samples over two frames == 5 samples in one go (running sums are sample-sequential)
+        ctx.render(flags=rt.FLAG_PATH_TRACE, spp=2, seed=9)
+        ctx.render(flags=rt.FLAG_PATH_TRACE | rt.FLAG_ACCUMULATE, spp=3, sample_first=2, seed=9)
+        acc_o, _ = orc.render_path(osc, view, 5, 4, seed=9)
+        assert bitwise_equal(ctx.read_accumulation(), acc_o)
+        assert bitwise_equal(ctx.read_radiance(), orc.resolve(acc_o, 5))
+        # moving the camera restarts the accumulation even with ACCUMULATE set (intent of src/scene.rs:94-96)
+        app.fly_cam_step(keys=rt.lib() and 1, dt=0.1)
+        m2, p2 = app.camera_view()
+        ctx.set_view(m2, p2, 64, 36)
+        ctx.render(flags=rt.FLAG_PATH_TRACE | rt.FLAG_ACCUMULATE, spp=2, seed=9)
+        acc2, _ = orc.render_path(osc, orc.make_view(m2, p2, 64, 36), 2, 4, seed=9)
+        assert bitwise_equal(ctx.read_accumulation(), acc2)
+
+
+def test_viewport_renders_only_its_rect_with_rebased_uv():
+    vp = (16, 8, 64, 36)
+    app = default_app(96, 60, viewport=vp)
+    scene = app.prepare_meshinfo()
+    rgba_o, prim_o, t_o, _ = orc.render_primary(oracle_scene(scene), oracle_view(app, vp), orc.FLAG_SHADOW)
+    ctx, rgba_g, prim_g, t_g = gpu_render(app, scene, rt.FLAG_SHADOW, viewport=vp)
+    assert bitwise_equal(rgba_g, rgba_o) and bitwise_equal(prim_g, prim_o) and bitwise_equal(t_g, t_o)
+    outside = np.ones((60, 96), bool)
+    outside[8:44, 16:80] = False
+    assert np.all(prim_g[outside] == rt.MISS_PRIM) and np.all(rgba_g[outside] == 0)
+    assert ctx.counters().rays_primary == 64 * 36
+    ctx.close()
+
+
+@pytest.mark.parametrize("count,tile", [(2, 64), (3, 16), (8, 32)])
+def test_tile_shards_partition_the_frame(count, tile):
+    from ray_tracing_amd import multi_gpu
+    app = default_app(200, 120)
+    scene = app.prepare_meshinfo()
+    ctx, full, prim_full, _ = gpu_render(app, scene, rt.FLAG_SHADOW)
+    owner = multi_gpu.tile_owner(200, 120, tile, count)
+    total = np.zeros_like(full)
+    rays = 0
+    for rank in range(count):
+        _, part, prim_part, _ = gpu_render(app, scene, rt.FLAG_SHADOW, ctx=ctx, shard_rank=rank, shard_count=count, tile_size=tile)
+        mine = owner == rank
+        assert bitwise_equal(part[mine], full[mine]) and np.all(part[~mine] == 0)
+        assert np.all(prim_part[~mine] == rt.MISS_PRIM)
+        total += part
+        rays += ctx.counters().rays_primary
+    assert np.array_equal(total, full) and rays == 200 * 120          # sum of shards == gather of tiles (-0 + 0 = +0: values, not bits)
+    ctx.close()
+
+
+def test_presentation_bgra8_srgb():
+    app = default_app(64, 36)
+    scene = app.prepare_meshinfo()
+    ctx, rgba, _, _ = gpu_render(app, scene, 0)
+    got = ctx.read_bgra8_srgb().astype(np.int16)
+    want = orc.encode_bgra8_srgb(rgba).astype(np.int16)
+    assert np.abs(got - want).max() <= 1          # powf on the device vs pow in double: at most 1 LSB at a rounding edge
+    assert (got != want).mean() < 0.01
+    ctx.close()
+
+
+def test_plugin_lifecycle_and_dirty_upload():
+    app = default_app(80, 45)
+    assert app.update() == rt.RT_NOT_READY                         # pipeline not created yet: silent skip (src/node.rs:52-56)
+    app.finish(0)                                                  # RayTracingPlugin::finish
+    assert app.update(flags=rt.FLAG_SHADOW) == rt.RT_OK
+    ctx = app.ctx()
+    scene = app.info()
+    rgba_o, prim_o, _, _ = orc.render_primary(oracle_scene(scene), oracle_view(app), orc.FLAG_SHADOW)
+    assert bitwise_equal(ctx.read_radiance(), rgba_o) and bitwise_equal(ctx.read_prim_ids(), prim_o)
+    app.rotate_tagged(0.25)                                        # `rotate` system (src/main.rs:122-126): scene changes
+    assert app.update(flags=rt.FLAG_SHADOW) == rt.RT_OK            # re-extracted, re-uploaded, BVH rebuilt
+    scene2 = app.info()
+    assert scene2.vertices.tobytes() != scene.vertices.tobytes()
+    rgba_o2, prim_o2, _, _ = orc.render_primary(oracle_scene(scene2), oracle_view(app), orc.FLAG_SHADOW)
+    assert bitwise_equal(ctx.read_radiance(), rgba_o2) and bitwise_equal(ctx.read_prim_ids(), prim_o2)
+    app.camera_set_graph(False)                                    # Tab: camera back on Core3d (src/main.rs:128-147)
+    assert app.update() == rt.RT_NOT_READY
+    app.close()
+
+
+def test_edge_cases_empty_scene_not_ready_and_bad_arguments():
+    with rt.Context(0) as ctx:
+        assert ctx.render() == rt.RT_NOT_READY                     # no scene, no view
+        empty = rt.Scene(np.zeros(0, rt.TRIANGLE), np.zeros(0, rt.MESH_INFO), np.zeros(0, rt.VERTEX), np.zeros(0, rt.MATERIAL))
+        ctx.upload_scene(empty)
+        assert ctx.render() == rt.RT_NOT_READY                     # still no view
+        ctx.set_view(np.eye(4, dtype=np.float32).ravel(), (0, 0, 0), 33, 17)     # ragged size (not a tile multiple)
+        for f in (0, rt.FLAG_SHADOW, rt.FLAG_BRUTE_FORCE, rt.FLAG_WAVE_TRAVERSAL, rt.FLAG_PERSISTENT, rt.FLAG_PATH_TRACE):
+            assert ctx.render(flags=f, spp=1) == rt.RT_OK
+            assert np.all(ctx.read_prim_ids() == rt.MISS_PRIM)
+        assert np.allclose(ctx.read_radiance()[..., :3], [0.5, 0.71, 0.86])       # path tracing: every path sees the sky
+        with pytest.raises(rt.RtError):
+            ctx.set_view(np.eye(4, dtype=np.float32).ravel(), (0, 0, 0), 0, 10)
+        with pytest.raises(rt.RtError):
+            ctx.set_view(np.eye(4, dtype=np.float32).ravel(), (0, 0, 0), 10, 10, (5, 5, 10, 10))
+        with pytest.raises(rt.RtError):
+            ctx.render(shard_rank=3, shard_count=2)
+        bad = rt.Scene(np.zeros(1, rt.TRIANGLE), np.zeros(0, rt.MESH_INFO), np.zeros(0, rt.VERTEX), np.zeros(0, rt.MATERIAL))
+        with pytest.raises(rt.RtError) as e:
+            ctx.upload_scene(bad)                                   # index 0 with no vertices
+        assert e.value.status == rt.RT_ERR_SCENE
+
+
+def test_degenerate_geometry_nan_vertices_and_zero_normals():
+    app = default_app(64, 36)
+    scene = app.prepare_meshinfo()
+    v = scene.vertices.copy()
+    v["pos"][30] = (np.nan, 0, 0)            # a plane-adjacent vertex of the second mesh? any vertex: its triangles vanish
+    v["norm"][100:110] = 0                   # zero normals -> NaN shading, same NaN on both sides
+    v["pos"][200] = v["pos"][201]            # zero-area triangle(s)
+    s2 = rt.Scene(scene.triangles, scene.meshes, v, scene.materials)
+    rgba_o, prim_o, t_o, _ = orc.render_primary(oracle_scene(s2), oracle_view(app), orc.FLAG_SHADOW)
+    for extra in (0, rt.FLAG_BRUTE_FORCE, rt.FLAG_WAVE_TRAVERSAL):
+        ctx, rgba_g, prim_g, t_g = gpu_render(app, s2, rt.FLAG_SHADOW | extra)
+        assert bitwise_equal(prim_g, prim_o) and bitwise_equal(t_g, t_o)
+        assert np.array_equal(np.isnan(rgba_g), np.isnan(rgba_o))
+        assert np.array_equal(np.nan_to_num(rgba_g), np.nan_to_num(rgba_o))
+        ctx.close()
+
+
+def test_axis_parallel_rays_and_rays_starting_on_geometry():
+    """Shadow rays are exactly (0,1,0) (two zero components, infinite reciprocals) and start 1e-3 off a
+    surface; path segments start ON a triangle. An orthographic-like top-down camera adds primary rays
+    with zero components. All must agree with the oracle bit for bit."""
+    app = default_app(48, 48)
+    app.camera_look_at((0.0, 8.0, 1e-7), (0, 0, 0), (0, 0, -1))
+    scene = app.prepare_meshinfo()
+    rgba_o, prim_o, t_o, _ = orc.render_primary(oracle_scene(scene), oracle_view(app), orc.FLAG_SHADOW)
+    ctx, rgba_g, prim_g, t_g = gpu_render(app, scene, rt.FLAG_SHADOW)
+    assert bitwise_equal(prim_g, prim_o) and bitwise_equal(t_g, t_o) and bitwise_equal(rgba_g, rgba_o)
+    ctx.close()
+
+
+def test_full_size_properties_on_the_bench_workload():
+    """At the bench's full size the oracle is too slow, so size-independent properties are checked:
+    (1) BVH path == reference-shaped brute-force loop on a random pixel sample (oracle on the sample),
+    (2) per-lane, wave-coherent and persistent kernels agree on the whole 1080p frame, bit for bit,
+    (3) the four tile shards of the frame add up to the frame, (4) counters are consistent."""
+    app = field_app(10000, 0x5EED0002, 1920, 1080)
+    app.camera_frame_scene(1.0)
+    scene = app.prepare_meshinfo()
+    ctx, rgba, prim, t = gpu_render(app, scene, rt.FLAG_SHADOW | rt.FLAG_COUNTERS)
+    c = ctx.counters()
+    hit = prim != rt.MISS_PRIM
+    assert c.rays_primary == 1920 * 1080 and c.rays_shadow == int(hit.sum())
+    assert 0.5 < hit.mean() < 0.8
+    assert np.all(rgba[~hit] == 0) and np.all(t[~hit] == 0) and np.all(t[hit] > 0)
+    # every reported primitive belongs to the scene and its mesh's material shades the pixel's colour family
+    assert prim[hit].max() < len(scene.triangles)
+    rng = np.random.default_rng(5)
+    pix = rng.choice(1920 * 1080, 1500, replace=False).astype(np.uint32)
+    rgba_o, prim_o, t_o, _ = orc.render_primary(oracle_scene(scene), oracle_view(app), orc.FLAG_SHADOW, threads=16, pixel_list=pix)
+    agree, rmse = parity(rgba.reshape(-1, 4)[pix], prim.ravel()[pix], rgba_o, prim_o)
+    assert agree >= 0.999 and rmse <= 1e-3, (agree, rmse)
+    assert bitwise_equal(prim.ravel()[pix], prim_o) and bitwise_equal(t.ravel()[pix], t_o)
+    for extra in (rt.FLAG_WAVE_TRAVERSAL, rt.FLAG_PERSISTENT):
+        _, rgba2, prim2, t2 = gpu_render(app, scene, rt.FLAG_SHADOW | extra, ctx=ctx)
+        assert bitwise_equal(prim2, prim) and bitwise_equal(t2, t) and bitwise_equal(rgba2, rgba)
+    total = np.zeros_like(rgba)
+    for rank in range(4):
+        _, part, _, _ = gpu_render(app, scene, rt.FLAG_SHADOW, ctx=ctx, shard_rank=rank, shard_count=4)
+        total += part
+    assert np.array_equal(total, rgba)
+    ctx.close()
+
+
+def test_soup_1m_triangles_sampled_parity():
+    app = soup_app(1389, 0x5EED0003, 1920, 1080)
+    app.camera_frame_scene(1.0)
+    scene = app.prepare_meshinfo()
+    assert len(scene.triangles) == 1000080 and len(scene.vertices) == 502818
+    ctx, rgba, prim, t = gpu_render(app, scene, rt.FLAG_SHADOW)
+    rng = np.random.default_rng(6)
+    pix = rng.choice(1920 * 1080, 4000, replace=False).astype(np.uint32)
+    rgba_o, prim_o, t_o, _ = orc.render_primary(oracle_scene(scene), oracle_view(app), orc.FLAG_SHADOW, threads=16, pixel_list=pix)
+    agree, rmse = parity(rgba.reshape(-1, 4)[pix], prim.ravel()[pix], rgba_o, prim_o)
+    assert agree >= 0.999 and rmse <= 1e-3, (agree, rmse)
+    # path tracing on the big scene: 1 spp, 4 segments, sampled rows against the oracle
+    assert ctx.render(flags=rt.FLAG_PATH_TRACE, spp=1, max_segments=4, seed=1) == rt.RT_OK
+    acc = ctx.read_accumulation()
+    assert np.all(acc[..., 3] == 1.0) and np.isfinite(acc).all()
+    ctx.close()

@@ -112,10 +112,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: ray_tracing_amd has no CPU fallback")
+    # rehearsal hooks (one-GPU box): BENCH_FORCE_DEVICE puts every rank on one card, BENCH_BACKEND=gloo
+    # replaces RCCL, which refuses two ranks on one device.  Never set by the driver.
+    if "BENCH_FORCE_DEVICE" in os.environ:
+        local_rank = int(os.environ["BENCH_FORCE_DEVICE"])
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        backend = os.environ.get("BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     import ray_tracing_amd as rt
 

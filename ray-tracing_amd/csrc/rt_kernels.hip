@@ -21,6 +21,7 @@
 #define RT_INF __builtin_huge_valf()
 
 struct f3 { float x, y, z; };
+typedef float v2f __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f3 F3(float x, float y, float z) { f3 r; r.x = x; r.y = y; r.z = z; return r; }
 __device__ __forceinline__ f3 sub(f3 a, f3 b) { return F3(a.x - b.x, a.y - b.y, a.z - b.z); }
 __device__ __forceinline__ f3 add(f3 a, f3 b) { return F3(a.x + b.x, a.y + b.y, a.z + b.z); }
@@ -92,6 +93,11 @@ __device__ __forceinline__ void traverse(const RtSceneDev &S, f3 o, f3 d, uint32
     h.hit = false; h.t = RT_INF; h.u = 0.0f; h.v = 0.0f; h.seq = 0xFFFFFFFFu; h.tri = 0xFFFFFFFFu; h.mesh = 0;
     if (S.n_nodes == 0) return;
     const f3 inv = F3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    // packed-f32 operands: on gfx950 a plain f32 VALU instruction issues in 4 cycles per wave64 and a
+    // v_pk_* one does two floats per lane in the same 4, so the 12 (plane - o) * inv of a node go as
+    // 6 v_pk_add + 6 v_pk_mul.  The node's 12 floats pair up as (x,y) (z,x) (y,z) (x,y) (z,x) (y,z).
+    const v2f oxy = {o.x, o.y}, ozx = {o.z, o.x}, oyz = {o.y, o.z};
+    const v2f ixy = {inv.x, inv.y}, izx = {inv.z, inv.x}, iyz = {inv.y, inv.z};
     int ovf[RT_STACK_OVF];
     int sp = 0;
     int cur = 0;
@@ -104,17 +110,18 @@ __device__ __forceinline__ void traverse(const RtSceneDev &S, f3 o, f3 d, uint32
             float4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3];
             if (COUNT) { c.nodes++; if ((threadIdx.x & 63u) == (uint32_t)__builtin_ctzll(__ballot(true))) c.wnodes++; }
             // slabs of both children; (plane - o) * inv keeps inf/NaN handling conservative
-            float ax0 = (q0.x - o.x) * inv.x, ax1 = (q0.w - o.x) * inv.x;
-            float ay0 = (q0.y - o.y) * inv.y, ay1 = (q1.x - o.y) * inv.y;
-            float az0 = (q0.z - o.z) * inv.z, az1 = (q1.y - o.z) * inv.z;
-            float bx0 = (q1.z - o.x) * inv.x, bx1 = (q2.y - o.x) * inv.x;
-            float by0 = (q1.w - o.y) * inv.y, by1 = (q2.z - o.y) * inv.y;
-            float bz0 = (q2.x - o.z) * inv.z, bz1 = (q2.w - o.z) * inv.z;
-            float tmin0 = fmaxf(fmaxf(fminf(ax0, ax1), fminf(ay0, ay1)), fminf(az0, az1));
-            float tmax0 = fminf(fminf(fmaxf(ax0, ax1), fmaxf(ay0, ay1)), fmaxf(az0, az1));
-            float tmin1 = fmaxf(fmaxf(fminf(bx0, bx1), fminf(by0, by1)), fminf(bz0, bz1));
-            float tmax1 = fminf(fminf(fmaxf(bx0, bx1), fmaxf(by0, by1)), fmaxf(bz0, bz1));
-            tmax0 *= 1.0000005f; tmax1 *= 1.0000005f;   // robust slab test (2 ulp)
+            v2f a0 = (v2f{q0.x, q0.y} - oxy) * ixy;   // lo0.x lo0.y
+            v2f a1 = (v2f{q0.z, q0.w} - ozx) * izx;   // lo0.z hi0.x
+            v2f a2 = (v2f{q1.x, q1.y} - oyz) * iyz;   // hi0.y hi0.z
+            v2f b0 = (v2f{q1.z, q1.w} - oxy) * ixy;   // lo1.x lo1.y
+            v2f b1 = (v2f{q2.x, q2.y} - ozx) * izx;   // lo1.z hi1.x
+            v2f b2 = (v2f{q2.z, q2.w} - oyz) * iyz;   // hi1.y hi1.z
+            float tmin0 = fmaxf(fmaxf(fminf(a0.x, a1.y), fminf(a0.y, a2.x)), fminf(a1.x, a2.y));
+            float tmin1 = fmaxf(fmaxf(fminf(b0.x, b1.y), fminf(b0.y, b2.x)), fminf(b1.x, b2.y));
+            v2f tmx = {fminf(fminf(fmaxf(a0.x, a1.y), fmaxf(a0.y, a2.x)), fmaxf(a1.x, a2.y)),
+                       fminf(fminf(fmaxf(b0.x, b1.y), fmaxf(b0.y, b2.x)), fmaxf(b1.x, b2.y))};
+            tmx = tmx * v2f{1.0000005f, 1.0000005f};   // robust slab test (2 ulp)
+            float tmax0 = tmx.x, tmax1 = tmx.y;
             bool h0 = tmin0 <= tmax0 && tmax0 >= 0.0f && tmin0 <= limit;
             bool h1 = tmin1 <= tmax1 && tmax1 >= 0.0f && tmin1 <= limit;
             int c0 = __float_as_int(q3.x), c1 = __float_as_int(q3.y);

@@ -64,6 +64,14 @@ int rt_upload_scene(rt_ctx *ctx,
                     const rt_vertex *vertices, size_t n_vertices,
                     const rt_material *materials, size_t n_materials);
 
+/* Same scene, moved vertices (the reference rebuilds and re-uploads everything every
+ * frame, src/ray_tracing.rs:113-168, and main.rs rotates the cube every frame, src/main.rs:122-126).
+ * Triangles, mesh ranges and materials must be the ones last uploaded; `vertices` replaces T3 and
+ * `meshes` T2 (their AABBs move with the vertices).  Leaf records are re-baked and the BVH boxes refitted
+ * instead of rebuilt.  Returns RT_ERR_SCENE if the topology differs (call rt_upload_scene instead). */
+int rt_update_vertices(rt_ctx *ctx, const rt_vertex *vertices, size_t n_vertices,
+                       const rt_mesh_info *meshes, size_t n_meshes);
+
 /* ---- view: replaces bind group 0 (View uniform, dynamic offset) and
  * set_camera_viewport (src/node.rs:58-62,71-76; ray_tracing.wgsl:5,176-177).
  * world_from_clip: column-major f32 4x4.  viewport = {x,y,w,h} or NULL for the full target. */
@@ -142,8 +150,9 @@ typedef struct {
     uint64_t n_nodes, n_triangles, n_meshes, n_vertices;
     uint32_t node_bytes, tri_bytes;  /* bytes per BVH node / per leaf triangle record */
     uint32_t max_depth, max_leaf;
-    double   build_ms;
-    double   sah_cost;
+    double   build_ms;               /* of the last build or refit */
+    double   sah_cost;               /* of the last full build */
+    uint32_t n_builds, n_refits;     /* since rt_create */
 } rt_bvh_info;
 int rt_get_bvh_info(rt_ctx *ctx, rt_bvh_info *out);
 /* Copy the flattened BVH out (host buffers sized from rt_get_bvh_info). */
@@ -154,6 +163,8 @@ int rt_read_bvh(rt_ctx *ctx, void *nodes, size_t node_bytes_total, void *tris, s
 typedef struct rt_host_bvh rt_host_bvh;
 int rt_host_bvh_build(const rt_triangle *triangles, size_t n_triangles, const rt_mesh_info *meshes, size_t n_meshes,
                       const rt_vertex *vertices, size_t n_vertices, int n_threads, rt_host_bvh **out, rt_bvh_info *info);
+int rt_host_bvh_refit(rt_host_bvh *bvh, const rt_triangle *triangles, size_t n_triangles,
+                      const rt_vertex *vertices, size_t n_vertices, int n_threads);
 int rt_host_bvh_copy(const rt_host_bvh *bvh, void *nodes, size_t node_bytes_total, void *tris, size_t tri_bytes_total);
 void rt_host_bvh_free(rt_host_bvh *bvh);
 

@@ -1,0 +1,75 @@
+//! UNBUILT SOURCE: `extern "C"` view of include/rt_amd.h for camms205/ray-tracing's src/node.rs and
+//! src/pipeline.rs.  Mechanical from the header; never compiled here (no Rust toolchain in the image).
+#![allow(non_camel_case_types)]
+use std::os::raw::{c_char, c_int, c_void};
+
+#[repr(C)]
+pub struct rt_ctx { _private: [u8; 0] }
+
+/// T1 Triangle, src/ray_tracing.rs:51-54 (12 B)
+#[repr(C)] #[derive(Clone, Copy, Default)]
+pub struct rt_triangle { pub indices: [u32; 3] }
+/// T2 MeshInfo, src/ray_tracing.rs:56-63 in its std430 layout (48 B)
+#[repr(C)] #[derive(Clone, Copy, Default)]
+pub struct rt_mesh_info {
+    pub first_tri: u32, pub tri_count: u32, pub material: u32, pub _pad0: u32,
+    pub aabb_min: [f32; 3], pub _pad1: f32,
+    pub aabb_max: [f32; 3], pub _pad2: f32,
+}
+/// T3 vertex, src/ray_tracing.rs:92-93 ([Vec3; 2] with 16-B stride, 32 B)
+#[repr(C)] #[derive(Clone, Copy, Default)]
+pub struct rt_vertex { pub pos: [f32; 3], pub _pad0: f32, pub norm: [f32; 3], pub _pad1: f32 }
+/// T4 SimpleMaterial, src/ray_tracing.rs:65-68 (16 B)
+#[repr(C)] #[derive(Clone, Copy, Default)]
+pub struct rt_material { pub color: [f32; 4] }
+
+#[repr(C)] #[derive(Clone, Copy, Default)]
+pub struct rt_render_params {
+    pub struct_size: u32, pub flags: u32, pub frame_count: u32, pub spp: u32, pub sample_first: u32,
+    pub max_segments: u32, pub seed: u32, pub stream_id: u32, pub shard_rank: u32, pub shard_count: u32,
+    pub tile_size: u32, pub _reserved: u32,
+}
+
+pub const RT_OK: c_int = 0;
+pub const RT_NOT_READY: c_int = 1;
+pub const RT_ERR_ARG: c_int = -1;
+pub const RT_ERR_HIP: c_int = -2;
+pub const RT_ERR_NO_GPU: c_int = -3;
+pub const RT_ERR_SCENE: c_int = -4;
+pub const RT_ERR_OOM: c_int = -5;
+
+pub const RT_FLAG_SHADOW: u32 = 0x0001;
+pub const RT_FLAG_NO_MESH_CULL: u32 = 0x0002;
+pub const RT_FLAG_BRUTE_FORCE: u32 = 0x0004;
+pub const RT_FLAG_COUNTERS: u32 = 0x0008;
+pub const RT_FLAG_PATH_TRACE: u32 = 0x0010;
+pub const RT_FLAG_ACCUMULATE: u32 = 0x0020;
+pub const RT_FLAG_TIME_KERNELS: u32 = 0x0040;
+pub const RT_FLAG_WAVE_TRAVERSAL: u32 = 0x0080;
+pub const RT_FLAG_PERSISTENT: u32 = 0x0100;
+
+extern "C" {
+    pub fn rt_create(device_ordinal: c_int, out: *mut *mut rt_ctx) -> c_int;
+    pub fn rt_destroy(ctx: *mut rt_ctx) -> c_int;
+    pub fn rt_set_stream(ctx: *mut rt_ctx, hip_stream: *mut c_void) -> c_int;
+    pub fn rt_upload_scene(ctx: *mut rt_ctx,
+        triangles: *const rt_triangle, n_triangles: usize, meshes: *const rt_mesh_info, n_meshes: usize,
+        vertices: *const rt_vertex, n_vertices: usize, materials: *const rt_material, n_materials: usize) -> c_int;
+    pub fn rt_update_vertices(ctx: *mut rt_ctx, vertices: *const rt_vertex, n_vertices: usize,
+        meshes: *const rt_mesh_info, n_meshes: usize) -> c_int;
+    pub fn rt_set_view(ctx: *mut rt_ctx, world_from_clip: *const f32, world_position: *const f32,
+        width: u32, height: u32, viewport: *const u32) -> c_int;
+    pub fn rt_render(ctx: *mut rt_ctx, params: *const rt_render_params) -> c_int;
+    pub fn rt_synchronize(ctx: *mut rt_ctx) -> c_int;
+    pub fn rt_read_radiance(ctx: *mut rt_ctx, rgba: *mut f32, n_floats: usize) -> c_int;
+    pub fn rt_read_prim_ids(ctx: *mut rt_ctx, prim: *mut u32, n: usize) -> c_int;
+    pub fn rt_read_hit_t(ctx: *mut rt_ctx, t: *mut f32, n: usize) -> c_int;
+    pub fn rt_read_bgra8_srgb(ctx: *mut rt_ctx, bgra: *mut u8, n_bytes: usize) -> c_int;
+    pub fn rt_read_accumulation(ctx: *mut rt_ctx, accum: *mut f32, n_floats: usize) -> c_int;
+    pub fn rt_device_buffers(ctx: *mut rt_ctx, d_radiance: *mut *mut c_void, d_prim: *mut *mut c_void,
+        d_accum: *mut *mut c_void) -> c_int;
+    pub fn rt_resolve_accumulation(ctx: *mut rt_ctx, total_samples: u32) -> c_int;
+    pub fn rt_last_error(ctx: *mut rt_ctx) -> *const c_char;
+    pub fn rt_status_string(status: c_int) -> *const c_char;
+    pub fn rt_version() -> *const c_char;
+}

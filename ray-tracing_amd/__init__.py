@@ -61,7 +61,7 @@ class BvhInfo(C.Structure):
     _fields_ = [("n_nodes", C.c_uint64), ("n_triangles", C.c_uint64), ("n_meshes", C.c_uint64),
                 ("n_vertices", C.c_uint64), ("node_bytes", C.c_uint32), ("tri_bytes", C.c_uint32),
                 ("max_depth", C.c_uint32), ("max_leaf", C.c_uint32), ("build_ms", C.c_double),
-                ("sah_cost", C.c_double)]
+                ("sah_cost", C.c_double), ("n_builds", C.c_uint32), ("n_refits", C.c_uint32)]
 
 
 class EntityView(C.Structure):
@@ -72,7 +72,7 @@ class EntityView(C.Structure):
 
 
 # every symbol include/rt_amd.h and include/rt_host.h declare
-RT_SYMBOLS = ["rt_create", "rt_destroy", "rt_set_stream", "rt_upload_scene", "rt_set_view", "rt_render",
+RT_SYMBOLS = ["rt_create", "rt_destroy", "rt_set_stream", "rt_upload_scene", "rt_update_vertices", "rt_host_bvh_refit", "rt_set_view", "rt_render",
               "rt_synchronize", "rt_read_radiance", "rt_read_prim_ids", "rt_read_hit_t", "rt_read_bgra8_srgb",
               "rt_read_accumulation", "rt_device_buffers", "rt_resolve_accumulation", "rt_get_counters",
               "rt_get_bvh_info", "rt_read_bvh", "rt_host_bvh_build", "rt_host_bvh_copy", "rt_host_bvh_free", "rt_last_error", "rt_status_string", "rt_version"]
@@ -100,6 +100,8 @@ def lib():
     sig = {
         "rt_create": (i, [i, C.POINTER(vp)]), "rt_destroy": (i, [vp]), "rt_set_stream": (i, [vp, vp]),
         "rt_upload_scene": (i, [vp, vp, sz, vp, sz, vp, sz, vp, sz]),
+        "rt_update_vertices": (i, [vp, vp, sz, vp, sz]),
+        "rt_host_bvh_refit": (i, [vp, vp, sz, vp, sz, i]),
         "rt_set_view": (i, [vp, fp, fp, u32, u32, C.POINTER(u32)]),
         "rt_render": (i, [vp, C.POINTER(RenderParams)]), "rt_synchronize": (i, [vp]),
         "rt_read_radiance": (i, [vp, vp, sz]), "rt_read_prim_ids": (i, [vp, vp, sz]),
@@ -164,14 +166,21 @@ class Scene:
         self.materials = np.ascontiguousarray(materials, dtype=MATERIAL)
 
 
-def host_bvh_build(scene, threads=0):
-    """BVH built on the host only (no GPU): returns (info, nodes, tri_records)."""
+def host_bvh_build(scene, threads=0, refit_to=None):
+    """BVH built on the host only (no GPU): returns (info, nodes, tri_records).
+    refit_to: a Scene with the same topology and moved vertices; the tree is refitted to it before the copy."""
     h, info = C.c_void_p(), BvhInfo()
     t, m, v = scene.triangles, scene.meshes, scene.vertices
     rc = lib().rt_host_bvh_build(t.ctypes.data, t.size, m.ctypes.data, m.size, v.ctypes.data, v.size, threads,
                                  C.byref(h), C.byref(info))
     if rc != RT_OK:
         raise RtError(rc, lib().rt_last_error(None).decode())
+    if refit_to is not None:
+        t2, v2 = refit_to.triangles, refit_to.vertices
+        rc = lib().rt_host_bvh_refit(h, t2.ctypes.data, t2.size, v2.ctypes.data, v2.size, threads)
+        if rc != RT_OK:
+            lib().rt_host_bvh_free(h)
+            raise RtError(rc, "rt_host_bvh_refit")
     nodes, recs = np.empty(info.n_nodes, dtype=BVH_NODE), np.empty(info.n_triangles, dtype=TRI_RECORD)
     lib().rt_host_bvh_copy(h, nodes.ctypes.data, nodes.nbytes, recs.ctypes.data, recs.nbytes)
     lib().rt_host_bvh_free(h)
@@ -217,6 +226,10 @@ class Context:
         t, m, v, c = scene.triangles, scene.meshes, scene.vertices, scene.materials
         return self._chk(lib().rt_upload_scene(self._h, t.ctypes.data, t.size, m.ctypes.data, m.size,
                                                v.ctypes.data, v.size, c.ctypes.data, c.size))
+
+    def update_vertices(self, scene):
+        v, m = scene.vertices, scene.meshes
+        return self._chk(lib().rt_update_vertices(self._h, v.ctypes.data, v.size, m.ctypes.data, m.size))
 
     def set_view(self, world_from_clip, world_position, width, height, viewport=None):
         m, p = _f32(world_from_clip, 16), _f32(world_position, 3)

@@ -288,3 +288,64 @@ void rt_bvh_build(const rt_triangle *tris, size_t n_tris, const rt_mesh_info *me
     out->sah_cost = sah;
     out->build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
 }
+
+bool rt_bvh_refit(RtBvhBuildResult *bvh, const rt_triangle *tris, const rt_vertex *verts, int n_threads) {
+    auto t0 = std::chrono::steady_clock::now();
+    const size_t n = bvh->recs.size();
+    if (n == 0) return true;
+    if (n_threads <= 0) {
+        n_threads = (int)std::thread::hardware_concurrency();
+        if (n_threads > 16) n_threads = 16;
+        if (n_threads < 1) n_threads = 1;
+    }
+    if (n < (size_t)1 << 16) n_threads = 1;
+    std::vector<float> blo(3 * n), bhi(3 * n);
+    std::atomic<bool> finite{true};
+    auto bake = [&](size_t b, size_t e) {
+        for (size_t i = b; i < e; ++i) {
+            RtTriRecord &R = bvh->recs[i];
+            const float *a = verts[tris[R.tri].indices[0]].pos;
+            const float *bb = verts[tris[R.tri].indices[1]].pos;
+            const float *c = verts[tris[R.tri].indices[2]].pos;
+            float amax = 0.0f, lo[3], hi[3];
+            bool ok = true;
+            for (int k = 0; k < 3; ++k) {
+                ok = ok && std::isfinite(a[k]) && std::isfinite(bb[k]) && std::isfinite(c[k]);
+                lo[k] = std::min(a[k], std::min(bb[k], c[k]));
+                hi[k] = std::max(a[k], std::max(bb[k], c[k]));
+                amax = std::max(amax, std::max(std::fabs(lo[k]), std::fabs(hi[k])));
+            }
+            if (!ok) { finite = false; return; }
+            float pad = 1e-5f * amax + 1e-30f;    // same padding rule as the build
+            for (int k = 0; k < 3; ++k) { blo[3 * i + k] = lo[k] - pad; bhi[3 * i + k] = hi[k] + pad; }
+            R.a[0] = a[0]; R.a[1] = a[1]; R.a[2] = a[2];
+            R.abx = bb[0] - a[0]; R.aby = bb[1] - a[1]; R.abz = bb[2] - a[2];
+            R.acx = c[0] - a[0]; R.acy = c[1] - a[1]; R.acz = c[2] - a[2];
+        }
+    };
+    if (n_threads == 1) bake(0, n);
+    else {
+        std::vector<std::thread> th;
+        for (int t = 0; t < n_threads; ++t) th.emplace_back(bake, n * t / n_threads, n * (t + 1) / n_threads);
+        for (auto &t : th) t.join();
+    }
+    if (!finite) return false;
+    auto child_box = [&](int32_t code, float *lo, float *hi) {
+        box_reset(lo, hi);
+        if (code >= 0) {
+            const RtBvhNode &C = bvh->nodes[code];
+            if (C.child0 != RT_CHILD_NONE) box_grow(lo, hi, C.lo0, C.hi0);
+            if (C.child1 != RT_CHILD_NONE) box_grow(lo, hi, C.lo1, C.hi1);
+        } else {
+            uint32_t v = (uint32_t)(~code), first = v >> 3, cnt = (v & 7u) + 1u;
+            for (uint32_t k = first; k < first + cnt; ++k) box_grow(lo, hi, &blo[3 * k], &bhi[3 * k]);
+        }
+    };
+    for (size_t i = bvh->nodes.size(); i-- > 0;) {     // children have larger indices than their parent
+        RtBvhNode &N = bvh->nodes[i];
+        if (N.child0 != RT_CHILD_NONE) child_box(N.child0, N.lo0, N.hi0);
+        if (N.child1 != RT_CHILD_NONE) child_box(N.child1, N.lo1, N.hi1);
+    }
+    bvh->build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return true;
+}

@@ -36,6 +36,9 @@ struct rt_ctx {
     void *d_nodes = nullptr, *d_recs = nullptr, *d_tris = nullptr, *d_meshes = nullptr, *d_verts = nullptr,
          *d_mats = nullptr;
     rt_bvh_info info{};
+    RtBvhBuildResult bvh_host;            // retained for refits (rt_update_vertices)
+    std::vector<rt_triangle> h_tris;      // topology of the uploaded scene
+    std::vector<rt_mesh_info> h_meshes;
 
     // view + framebuffers
     bool has_view = false;
@@ -288,6 +291,15 @@ int rt_host_bvh_copy(const rt_host_bvh *h, void *nodes, size_t nb, void *tris, s
     if (tris && tb) std::memcpy(tris, h->r.recs.data(), tb);
     return RT_OK;
 }
+int rt_host_bvh_refit(rt_host_bvh *h, const rt_triangle *tris, size_t n_tris, const rt_vertex *verts, size_t n_verts,
+                      int n_threads) {
+    if (!h || (n_tris && !tris) || (n_verts && !verts)) return RT_ERR_ARG;
+    for (const RtTriRecord &R : h->r.recs) {
+        if (R.tri >= n_tris) return RT_ERR_SCENE;
+        for (int k = 0; k < 3; ++k) if (tris[R.tri].indices[k] >= n_verts) return RT_ERR_SCENE;
+    }
+    return rt_bvh_refit(&h->r, tris, verts, n_threads) ? RT_OK : RT_ERR_SCENE;
+}
 void rt_host_bvh_free(rt_host_bvh *h) { delete h; }
 
 int rt_upload_scene(rt_ctx *c, const rt_triangle *tris, size_t n_tris, const rt_mesh_info *meshes, size_t n_meshes,
@@ -333,10 +345,42 @@ int rt_upload_scene(rt_ctx *c, const rt_triangle *tris, size_t n_tris, const rt_
     c->S.n_meshes = (uint32_t)n_meshes;
     c->S.n_verts = (uint32_t)n_verts;
     c->S.n_mats = (uint32_t)n_mats;
+    uint32_t nb = c->info.n_builds + 1, nr = c->info.n_refits;
     fill_info(&c->info, bvh, n_meshes, n_verts);
+    c->info.n_builds = nb; c->info.n_refits = nr;
+    c->h_tris.assign(tris, tris + n_tris);
+    c->h_meshes.assign(meshes, meshes + n_meshes);
+    c->bvh_host = std::move(bvh);
     c->has_scene = true;
     c->accum_samples = 0;
     c->coverage_sig = 0;
+    return RT_OK;
+}
+
+int rt_update_vertices(rt_ctx *c, const rt_vertex *verts, size_t n_verts, const rt_mesh_info *meshes, size_t n_meshes) {
+    if (!c) return RT_ERR_ARG;
+    if (!c->has_scene) return RT_NOT_READY;
+    if ((n_verts && !verts) || (n_meshes && !meshes)) return fail(c, RT_ERR_ARG, "rt_update_vertices: NULL array");
+    if (n_verts != c->S.n_verts || n_meshes != c->h_meshes.size())
+        return fail(c, RT_ERR_SCENE, "rt_update_vertices: vertex or mesh count differs from the uploaded scene");
+    for (size_t m = 0; m < n_meshes; ++m)
+        if (meshes[m].first_tri != c->h_meshes[m].first_tri || meshes[m].tri_count != c->h_meshes[m].tri_count)
+            return fail(c, RT_ERR_SCENE, "rt_update_vertices: mesh triangle ranges differ from the uploaded scene");
+    if (c->bvh_host.dropped)   // triangles left out of the tree at build time could have become valid
+        return fail(c, RT_ERR_SCENE, "rt_update_vertices: the built tree dropped non-finite triangles, rebuild with rt_upload_scene");
+    if (!rt_bvh_refit(&c->bvh_host, c->h_tris.data(), verts, 0))
+        return fail(c, RT_ERR_SCENE, "rt_update_vertices: non-finite vertex, rebuild with rt_upload_scene");
+    HIPCHK(c, hipSetDevice(c->device));
+    const RtBvhBuildResult &b = c->bvh_host;
+    if (!b.nodes.empty()) HIPCHK(c, hipMemcpyAsync(c->d_nodes, b.nodes.data(), b.nodes.size() * sizeof(RtBvhNode), hipMemcpyHostToDevice, c->stream));
+    if (!b.recs.empty()) HIPCHK(c, hipMemcpyAsync(c->d_recs, b.recs.data(), b.recs.size() * sizeof(RtTriRecord), hipMemcpyHostToDevice, c->stream));
+    if (n_verts) HIPCHK(c, hipMemcpyAsync(c->d_verts, verts, n_verts * sizeof(rt_vertex), hipMemcpyHostToDevice, c->stream));
+    if (n_meshes) HIPCHK(c, hipMemcpyAsync(c->d_meshes, meshes, n_meshes * sizeof(rt_mesh_info), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));   // host arrays are borrowed for this call only
+    c->h_meshes.assign(meshes, meshes + n_meshes);
+    c->info.build_ms = b.build_ms;
+    c->info.n_refits += 1;
+    c->accum_dirty = true;                        // geometry moved: accumulation restarts
     return RT_OK;
 }
 

@@ -4,8 +4,10 @@
 #include <hip/hip_runtime_api.h>
 #include "rt_layout.h"
 
+#ifndef RT_BLOCK
 #define RT_BLOCK 256          // 4 waves; each wave owns one 8x8 pixel tile
-#define RT_WORK_TILE 16       // a block covers 16x16 pixels
+#define RT_WORK_TILE 16       // a block covers 16x16 pixels (8 for RT_BLOCK 64)
+#endif
 
 // Number of blocks a primary/path-start launch needs for this shard description.
 uint32_t rtk_primary_blocks(const RtShardDev &sh);

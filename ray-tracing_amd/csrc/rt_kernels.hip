@@ -358,8 +358,8 @@ __device__ __forceinline__ bool pixel_of_thread(const RtViewDev &V, const RtShar
     uint32_t g = sh.rank + k * (sh.count ? sh.count : 1u);
     uint32_t gx = g % sh.tiles_x, gy = g / sh.tiles_x;
     uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u;
-    uint32_t x = gx * sh.tile + (s % sub) * RT_WORK_TILE + (wave & 1u) * 8u + (lane & 7u);
-    uint32_t y = gy * sh.tile + (s / sub) * RT_WORK_TILE + (wave >> 1) * 8u + (lane >> 3);
+    uint32_t x = gx * sh.tile + (s % sub) * RT_WORK_TILE + (wave % (RT_WORK_TILE / 8u)) * 8u + (lane & 7u);
+    uint32_t y = gy * sh.tile + (s / sub) * RT_WORK_TILE + (wave / (RT_WORK_TILE / 8u)) * 8u + (lane >> 3);
     px = V.vx + x; py = V.vy + y;
     return x < V.vw && y < V.vh;
 }
@@ -394,7 +394,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_MIN_WAVES) void k_primary(RtSceneDev S
                                                       uint32_t flags, float4 *__restrict__ rgba,
                                                       uint32_t *__restrict__ prim, float *__restrict__ tout,
                                                       unsigned long long *__restrict__ counters) {
-    __shared__ int s_stack[PACKET ? 4 * (RT_MAX_DEPTH + 2) : RT_STACK_LDS * RT_BLOCK];
+    __shared__ int s_stack[PACKET ? (RT_BLOCK / 64) * (RT_MAX_DEPTH + 2) : RT_STACK_LDS * RT_BLOCK];
     int *stk = PACKET ? s_stack + (threadIdx.x >> 6) * (RT_MAX_DEPTH + 2) : s_stack + threadIdx.x;
     uint32_t px, py;
     bool active = pixel_of_thread(V, sh, nb, px, py);

@@ -425,12 +425,27 @@ int RayTracingPassNode::run(const View &view, World &world, RayTracingPipeline &
     sig = fnv(info.materials.data(), info.materials.size() * sizeof(SimpleMaterial), sig);
     sig ^= info.triangles.size() * 0x9E3779B97F4A7C15ull;
     if (sig == 0) sig = 1;
+    uint64_t topo = 0xCBF29CE484222325ull;
+    topo = fnv(info.triangles.data(), info.triangles.size() * sizeof(Triangle), topo);
+    topo = fnv(info.materials.data(), info.materials.size() * sizeof(SimpleMaterial), topo);
+    for (const MeshInfo &mi : info.meshes) topo = fnv(&mi, 12, topo);   // first_tri, tri_count, material
+    topo ^= info.vertices.size() * 0x9E3779B97F4A7C15ull;
+    if (topo == 0) topo = 1;
+    if (sig != uploaded_signature && topo == topology_signature && uploaded_signature != 0) {
+        // only vertices / mesh boxes moved (main.rs rotates the cube every frame,
+        // src/main.rs:122-126): re-bake records and refit the BVH instead of rebuilding it
+        int rc = rt_update_vertices(pipeline.ctx, info.vertices.data(), info.vertices.size(), info.meshes.data(),
+                                    info.meshes.size());
+        if (rc == RT_OK) uploaded_signature = sig;
+        else if (rc != RT_ERR_SCENE) return rc;
+    }
     if (sig != uploaded_signature) {
         int rc = rt_upload_scene(pipeline.ctx, info.triangles.data(), info.triangles.size(), info.meshes.data(),
                                  info.meshes.size(), info.vertices.data(), info.vertices.size(),
                                  info.materials.data(), info.materials.size());
         if (rc != RT_OK) return rc;
         uploaded_signature = sig;
+        topology_signature = topo;
     }
     uint32_t vp[4] = {view.viewport.x, view.viewport.y, view.viewport.w, view.viewport.h};
     int rc = rt_set_view(pipeline.ctx, view.world_from_clip, view.world_position, view.width, view.height,

@@ -118,6 +118,7 @@ struct RayTracingPipeline {
 // src/node.rs:18-80
 struct RayTracingPassNode {
     uint64_t uploaded_signature = 0;   // scene re-upload only when the arrays change
+    uint64_t topology_signature = 0;   // triangles + mesh ranges + materials: unchanged => refit instead of rebuild
     // Returns RT_OK, or RT_NOT_READY when the pipeline is not ready (silent skip, :52-56).
     int run(const View &view, World &world, RayTracingPipeline &pipeline, const rt_render_params *params);
 };

@@ -140,15 +140,56 @@ def test_plugin_lifecycle_and_dirty_upload():
     scene = app.info()
     rgba_o, prim_o, _, _ = orc.render_primary(oracle_scene(scene), oracle_view(app), orc.FLAG_SHADOW)
     assert bitwise_equal(ctx.read_radiance(), rgba_o) and bitwise_equal(ctx.read_prim_ids(), prim_o)
-    app.rotate_tagged(0.25)                                        # `rotate` system (src/main.rs:122-126): scene changes
-    assert app.update(flags=rt.FLAG_SHADOW) == rt.RT_OK            # re-extracted, re-uploaded, BVH rebuilt
-    scene2 = app.info()
-    assert scene2.vertices.tobytes() != scene.vertices.tobytes()
-    rgba_o2, prim_o2, _, _ = orc.render_primary(oracle_scene(scene2), oracle_view(app), orc.FLAG_SHADOW)
-    assert bitwise_equal(ctx.read_radiance(), rgba_o2) and bitwise_equal(ctx.read_prim_ids(), prim_o2)
+    assert (ctx.bvh_info().n_builds, ctx.bvh_info().n_refits) == (1, 0)
+    for frame in range(1, 4):
+        app.rotate_tagged(0.25)                                    # `rotate` system (src/main.rs:122-126): vertices move
+        assert app.update(flags=rt.FLAG_SHADOW) == rt.RT_OK        # re-extracted; records re-baked, BVH refitted (8f item 1)
+        scene2 = app.info()
+        assert scene2.vertices.tobytes() != scene.vertices.tobytes()
+        rgba_o2, prim_o2, _, _ = orc.render_primary(oracle_scene(scene2), oracle_view(app), orc.FLAG_SHADOW)
+        assert bitwise_equal(ctx.read_radiance(), rgba_o2) and bitwise_equal(ctx.read_prim_ids(), prim_o2)
+        assert (ctx.bvh_info().n_builds, ctx.bvh_info().n_refits) == (1, frame)
+    assert app.update(flags=rt.FLAG_SHADOW) == rt.RT_OK            # nothing moved: neither upload nor refit
+    assert (ctx.bvh_info().n_builds, ctx.bvh_info().n_refits) == (1, 3)
+    m = app.add_material((0.1, 0.9, 0.1, 1.0))
+    app.spawn(app.add_icosphere(0.4, 2), m, translation=(0.0, 1.5, 0.0))   # topology changes: full rebuild
+    assert app.update(flags=rt.FLAG_SHADOW) == rt.RT_OK
+    assert ctx.bvh_info().n_builds == 2
+    scene3 = app.info()
+    rgba_o3, prim_o3, _, _ = orc.render_primary(oracle_scene(scene3), oracle_view(app), orc.FLAG_SHADOW)
+    assert bitwise_equal(ctx.read_radiance(), rgba_o3) and bitwise_equal(ctx.read_prim_ids(), prim_o3)
     app.camera_set_graph(False)                                    # Tab: camera back on Core3d (src/main.rs:128-147)
     assert app.update() == rt.RT_NOT_READY
     app.close()
+
+
+def test_update_vertices_refit_matches_a_rebuild_and_rejects_other_topologies():
+    app = soup_app(30, 0x5EED0003, 160, 90, subdivisions=3)
+    app.camera_frame_scene(1.0)
+    scene = app.prepare_meshinfo()
+    with rt.Context(0) as ctx:
+        ctx.upload_scene(scene)
+        moved = rt.Scene(scene.triangles, scene.meshes.copy(), scene.vertices.copy(), scene.materials)
+        rng = np.random.default_rng(3)
+        shift = rng.uniform(-3, 3, size=(len(moved.meshes), 3)).astype(np.float32)      # every sphere drifts
+        for k, mi in enumerate(moved.meshes):
+            tri = moved.triangles["indices"][mi["first_tri"]:mi["first_tri"] + mi["tri_count"]]
+            vs = np.unique(tri)
+            moved.vertices["pos"][vs] += shift[k]
+            moved.meshes["aabb_min"][k] += shift[k]
+            moved.meshes["aabb_max"][k] += shift[k]
+        ctx.update_vertices(moved)
+        m, p = app.camera_view()
+        ctx.set_view(m, p, 160, 90)
+        assert ctx.render(flags=rt.FLAG_SHADOW) == rt.RT_OK
+        rgba_o, prim_o, t_o, _ = orc.render_primary(oracle_scene(moved), oracle_view(app), orc.FLAG_SHADOW)
+        assert bitwise_equal(ctx.read_prim_ids(), prim_o) and bitwise_equal(ctx.read_hit_t(), t_o)
+        assert bitwise_equal(ctx.read_radiance(), rgba_o)
+        assert ctx.bvh_info().n_refits == 1
+        fewer = rt.Scene(scene.triangles, scene.meshes[:-1], scene.vertices, scene.materials)
+        with pytest.raises(rt.RtError) as e:
+            ctx.update_vertices(fewer)
+        assert e.value.status == rt.RT_ERR_SCENE
 
 
 def test_edge_cases_empty_scene_not_ready_and_bad_arguments():

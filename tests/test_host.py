@@ -227,6 +227,24 @@ def test_bvh_builder_layout_is_a_valid_hierarchy():
         _check_bvh(scene, nodes, recs, info)
 
 
+def test_bvh_refit_keeps_a_valid_hierarchy_over_moved_vertices():
+    import sys
+    sys.setrecursionlimit(10000)
+    app = default_app()
+    scene = app.prepare_meshinfo()
+    app.rotate_tagged(0.7)                       # the `rotate` system moves the cube (src/main.rs:122-126)
+    moved = app.prepare_meshinfo()
+    assert moved.triangles.tobytes() == scene.triangles.tobytes() and moved.vertices.tobytes() != scene.vertices.tobytes()
+    info, nodes, recs = rt.host_bvh_build(scene, threads=2, refit_to=moved)
+    _check_bvh(moved, nodes, recs, info)         # boxes bound the MOVED triangles, records re-baked
+    _, nodes0, recs0 = rt.host_bvh_build(scene, threads=2)
+    assert np.array_equal(nodes["child0"], nodes0["child0"]) and np.array_equal(recs["seq"], recs0["seq"])   # topology kept
+    bad = rt.Scene(moved.triangles, moved.meshes, moved.vertices.copy(), moved.materials)
+    bad.vertices["pos"][3] = (np.inf, 0, 0)
+    with pytest.raises(rt.RtError):
+        rt.host_bvh_build(scene, refit_to=bad)   # a non-finite vertex needs a rebuild
+
+
 def test_bvh_builder_edge_cases():
     empty = rt.Scene(np.zeros(0, rt.TRIANGLE), np.zeros(0, rt.MESH_INFO), np.zeros(0, rt.VERTEX), np.zeros(0, rt.MATERIAL))
     info, nodes, recs = rt.host_bvh_build(empty)

@@ -1,5 +1,8 @@
+"""Experiment script (GPU): not a test, not collected by pytest."""
+import os
 import sys
-sys.path.insert(0,'/root/repo'); sys.path.insert(0,'/root/repo/oracle')
+_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [_ROOT, os.path.join(_ROOT, "oracle")]
 import numpy as np, ray_tracing_amd as rt
 ctx = rt.Context(0)
 for kind,n,seed in (("field",10000,0x5EED0002),("soup",1389,0x5EED0003)):

@@ -29,16 +29,19 @@ CAMERA_RADII = 1.0
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measured copy)
 
 WORKLOADS = {
-    # name: (kind, count, seed, width, height, flags_shadow)
-    "sphere_field_10k_1080p_primary_shadow": ("field", 10000, 0x5EED0002, 1920, 1080),
+    # name: (kind, count, seed, width, height[, spp, max_segments])   spp > 0 => path tracing (wgsl:180-202 shape)
+    "sphere_field_10k_1080p_primary_shadow": ("field", 10000, 0x5EED0002, 1920, 1080),     # configs[1], the default
     "soup_1m_1080p_primary_shadow": ("soup", 1389, 0x5EED0003, 1920, 1080),
+    "soup_1m_1080p_4spp": ("soup", 1389, 0x5EED0003, 1920, 1080, 4, 1),                    # configs[2]: jittered primaries
+    "soup_1m_4k_path_4spp_4seg": ("soup", 1389, 0x5EED0003, 3840, 2160, 4, 4),             # configs[3] per 4 of its 64 spp
+    "soup_10m_1080p_path_1spp_8seg": ("soup", 13889, 0x5EED0005, 1920, 1080, 1, 8),        # configs[4] scene, one GPU
     "default_640x360": ("default", 0, 0, 640, 360),
     "sphere_field_200_small": ("field", 200, 0x5EED0002, 640, 360),
 }
 
 
 def build_app(rt, workload, rank=0, world=1):
-    kind, count, seed, W, H = WORKLOADS[workload]
+    kind, count, seed, W, H = WORKLOADS[workload][:5]
     app = rt.App()
     # Camera: eye ON the scene's bounding sphere (1.0 radii) looking at the centroid.  SURVEY 8d
     # suggested 2.5 radii, but from there only 14 % of the primary rays hit anything (measured),
@@ -140,16 +143,24 @@ def main():
     ctx.set_view(m, p, W, H)
     info = ctx.bvh_info()
 
-    flags = rt.FLAG_SHADOW
+    wl = WORKLOADS[args.workload]
+    spp, segs = (wl[5], wl[6]) if len(wl) > 5 else (0, 0)
+    flags = rt.FLAG_PATH_TRACE if spp else rt.FLAG_SHADOW
     shard = dict(shard_rank=rank, shard_count=world, tile_size=64) if tiles else {}
+    if spp:
+        shard.update(spp=spp, max_segments=segs, seed=1, stream_id=rank)
 
     # instrumented launch (same view): counted node visits / triangle tests for the roofline
     ctx.render(flags=flags | rt.FLAG_COUNTERS, **shard)
     cnt = ctx.counters()
-    rays_step = cnt.rays_primary + cnt.rays_shadow
+    rays_step = cnt.rays_primary + cnt.rays_shadow + cnt.rays_bounce
     hits = cnt.rays_shadow
-    alg_bytes = (cnt.node_visits * info.node_bytes + cnt.tri_tests * info.tri_bytes + cnt.mesh_aabb_tests * 32 +
-                 cnt.rays_primary * 24 + hits * 80)
+    if spp:   # path tracing: 44 B of path state written + read per continued segment, 16 B accumulation RMW per path end
+        alg_bytes = (cnt.node_visits * info.node_bytes + cnt.tri_tests * info.tri_bytes + cnt.mesh_aabb_tests * 32 +
+                     cnt.rays_bounce * (88 + 80) + cnt.rays_primary * 32)
+    else:
+        alg_bytes = (cnt.node_visits * info.node_bytes + cnt.tri_tests * info.tri_bytes + cnt.mesh_aabb_tests * 32 +
+                     cnt.rays_primary * 24 + hits * 80)
 
     rad_t = None
     if tiles:
@@ -181,7 +192,7 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     kc = ctx.counters()                        # sums the per-launch HIP event pairs
-    kernel_ms = kc.kernel_ms / max(kc.kernel_launches, 1)
+    kernel_ms = kc.kernel_ms / (args.steps if spp else max(kc.kernel_launches, 1))   # per launch; per frame when path tracing
 
     total_rays = float(rays_step)
     if world > 1:
@@ -210,19 +221,20 @@ def main():
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True, "scaling": "strong" if tiles else "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": args.workload, "resolution": f"{W}x{H}", "rays": "primary+shadow, 1 spp",
+            "config": {"workload": args.workload, "resolution": f"{W}x{H}", "rays": (f"path tracing, {spp} spp, <= {segs} segments" if spp else "primary+shadow, 1 spp"),
                        "triangles": int(info.n_triangles), "bvh_nodes": int(info.n_nodes),
                        "rays_per_step_rank0": int(rays_step),
                        "primary_hit_fraction": round(hits / max(cnt.rays_primary, 1), 4), "camera_radii": CAMERA_RADII,
                        "parallelism": ("tiles64-roundrobin+allreduce" if tiles else f"frames-dp{world}")},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                         "kernel": "k_primary<false, false>", "kernel_ms": round(kernel_ms, 4),
+                         "kernel": ("k_path_start+k_path_bounce (whole frame)" if spp else "k_primary<false, false>"),
+                         "kernel_ms": round(kernel_ms, 4),
                          "algorithmic_bytes_per_launch": int(alg_bytes),
                          "node_visits": int(cnt.node_visits), "tri_tests": int(cnt.tri_tests),
                          "bytes_per_ray": round(alg_bytes / max(rays_step, 1), 1)},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and not spp:
             import oracle_py as orc
             view = orc.make_view(m, p, W, H)
             cb, pix, rgba_o, prim_o = cpu_baseline(orc, scene, view, W, H, flags, args.cpu_seconds)

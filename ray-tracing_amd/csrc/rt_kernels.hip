@@ -754,7 +754,7 @@ __device__ __forceinline__ bool path_segment(const RtSceneDev &S, uint32_t flags
 }
 
 template <bool COUNT>
-__global__ __launch_bounds__(RT_BLOCK) void k_path_start(RtSceneDev S, RtViewDev V, RtShardDev sh, uint32_t nb,
+__global__ __launch_bounds__(RT_BLOCK, RT_MIN_WAVES) void k_path_start(RtSceneDev S, RtViewDev V, RtShardDev sh, uint32_t nb,
                                                          uint32_t flags, uint32_t sample, uint32_t seed,
                                                          uint32_t stream_id, uint32_t max_segments,
                                                          float4 *__restrict__ accum, RtPathQueue qo,
@@ -794,7 +794,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_path_start(RtSceneDev S, RtViewDev
 }
 
 template <bool COUNT>
-__global__ __launch_bounds__(RT_BLOCK) void k_path_bounce(RtSceneDev S, uint32_t flags, int is_last,
+__global__ __launch_bounds__(RT_BLOCK, RT_MIN_WAVES) void k_path_bounce(RtSceneDev S, uint32_t flags, int is_last,
                                                           float4 *__restrict__ accum, RtPathQueue qi, RtPathQueue qo,
                                                           unsigned long long *__restrict__ counters, int qi_ctr,
                                                           int qo_ctr) {

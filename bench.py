@@ -249,6 +249,7 @@ def main():
         print(json.dumps(out), flush=True)
     ctx.close()
     if world > 1:
+        dist.barrier()                 # rank 0's CPU baseline is done before anyone tears the group down
         dist.destroy_process_group()
 
 

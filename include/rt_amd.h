@@ -143,6 +143,7 @@ typedef struct {
     uint32_t _pad;
     uint64_t wave_node_iters;    /* wave-level trips of the node loop / of the triangle loop */
     uint64_t wave_tri_iters;     /*   (RT_FLAG_COUNTERS, per-lane kernels): lane utilisation */
+    uint64_t wave_alive_lanes;   /* sum over node-loop trips of the wave's unfinished rays */
 } rt_counters;
 int rt_get_counters(rt_ctx *ctx, rt_counters *out);
 

@@ -54,7 +54,7 @@ class Counters(C.Structure):
     _fields_ = [("rays_primary", C.c_uint64), ("rays_shadow", C.c_uint64), ("rays_bounce", C.c_uint64),
                 ("node_visits", C.c_uint64), ("tri_tests", C.c_uint64), ("mesh_aabb_tests", C.c_uint64),
                 ("kernel_ms", C.c_double), ("kernel_launches", C.c_uint32), ("_pad", C.c_uint32),
-                ("wave_node_iters", C.c_uint64), ("wave_tri_iters", C.c_uint64)]
+                ("wave_node_iters", C.c_uint64), ("wave_tri_iters", C.c_uint64), ("wave_alive_lanes", C.c_uint64)]
 
 
 class BvhInfo(C.Structure):

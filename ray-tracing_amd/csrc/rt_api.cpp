@@ -538,6 +538,7 @@ int rt_get_counters(rt_ctx *c, rt_counters *out) {
     c->counters.mesh_aabb_tests = c->h_cnt[RT_CNT_MESH];
     c->counters.wave_node_iters = c->h_cnt[RT_CNT_WNODE];
     c->counters.wave_tri_iters = c->h_cnt[RT_CNT_WTRI];
+    c->counters.wave_alive_lanes = c->h_cnt[RT_CNT_WALIVE];
     c->counters.kernel_ms = ms;
     *out = c->counters;
     // timing accumulates between two rt_get_counters calls; ray counters are of the last render

@@ -80,7 +80,7 @@ struct Hit {
     bool hit;
 };
 
-struct Cnt { uint32_t nodes, tris, meshes, wnodes, wtris; };   // w*: wave-level loop trips (first active lane counts)
+struct Cnt { uint32_t nodes, tris, meshes, wnodes, wtris, walive; };   // w*: wave-level loop trips (first active lane counts)
 
 // ---- BVH traversal (build-side design; reference src/bvh.rs:1 is empty) ----------------------
 // Closest hit with the reference's tie rule restated order-independently: among equal t the
@@ -105,10 +105,11 @@ __device__ __forceinline__ void traverse(const RtSceneDev &S, f3 o, f3 d, uint32
     bool last_ok = true;
     float limit = RT_INF;
     for (;;) {
+        uint32_t alive_now = COUNT ? (uint32_t)__builtin_popcountll(__ballot(true)) : 0u;   // rays of the wave not finished yet
         if (cur >= 0) {
             const float4 *p = reinterpret_cast<const float4 *>(S.nodes + cur);
             float4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3];
-            if (COUNT) { c.nodes++; if ((threadIdx.x & 63u) == (uint32_t)__builtin_ctzll(__ballot(true))) c.wnodes++; }
+            if (COUNT) { c.nodes++; if ((threadIdx.x & 63u) == (uint32_t)__builtin_ctzll(__ballot(true))) { c.wnodes++; c.walive += alive_now; } }
             // slabs of both children; (plane - o) * inv keeps inf/NaN handling conservative
             v2f a0 = (v2f{q0.x, q0.y} - oxy) * ixy;   // lo0.x lo0.y
             v2f a1 = (v2f{q0.z, q0.w} - ozx) * izx;   // lo0.z hi0.x
@@ -398,7 +399,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_MIN_WAVES) void k_primary(RtSceneDev S
     int *stk = PACKET ? s_stack + (threadIdx.x >> 6) * (RT_MAX_DEPTH + 2) : s_stack + threadIdx.x;
     uint32_t px, py;
     bool active = pixel_of_thread(V, sh, nb, px, py);
-    Cnt c; c.nodes = 0; c.tris = 0; c.meshes = 0; c.wnodes = 0; c.wtris = 0;
+    Cnt c; c.nodes = 0; c.tris = 0; c.meshes = 0; c.wnodes = 0; c.wtris = 0; c.walive = 0;
     f3 o = F3(0.0f, 0.0f, 0.0f), d = F3(0.0f, 0.0f, 1.0f);
     if (active) ray_gen(V, px, py, o, d);
     Hit h;
@@ -436,6 +437,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_MIN_WAVES) void k_primary(RtSceneDev S
         wave_sum(counters + RT_CNT_MESH, c.meshes);
         wave_sum(counters + RT_CNT_WNODE, c.wnodes);
         wave_sum(counters + RT_CNT_WTRI, c.wtris);
+        wave_sum(counters + RT_CNT_WALIVE, c.walive);
     }
 }
 
@@ -577,7 +579,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_PERSIST_MIN_WAVES) void k_primary_pers
     int *stk = s_stack + threadIdx.x;
     int ovf[RT_STACK_OVF];
     const uint32_t lane = threadIdx.x & 63u;
-    Cnt c; c.nodes = 0; c.tris = 0; c.meshes = 0; c.wnodes = 0; c.wtris = 0;
+    Cnt c; c.nodes = 0; c.tris = 0; c.meshes = 0; c.wnodes = 0; c.wtris = 0; c.walive = 0;
     uint32_t n_primary = 0, n_shadow = 0;
     int state = 0;                 // 0 idle, 1 primary ray, 2 shadow ray
     bool exhausted = false;        // wave-uniform: the work counter has run past `total`
@@ -763,7 +765,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_MIN_WAVES) void k_path_start(RtSceneDe
     int *stk = s_stack + threadIdx.x;
     uint32_t px, py;
     bool active = pixel_of_thread(V, sh, nb, px, py);
-    Cnt c; c.nodes = 0; c.tris = 0; c.meshes = 0; c.wnodes = 0; c.wtris = 0;
+    Cnt c; c.nodes = 0; c.tris = 0; c.meshes = 0; c.wnodes = 0; c.wtris = 0; c.walive = 0;
     bool alive = false;
     f3 o, d, col; uint32_t rng = 0, pixel = 0;
     if (active) {
@@ -804,7 +806,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_MIN_WAVES) void k_path_bounce(RtSceneD
     uint32_t i = blockIdx.x * RT_BLOCK + threadIdx.x;
     if (blockIdx.x * RT_BLOCK >= n) return;            // whole block past the queue end
     bool active = i < n;
-    Cnt c; c.nodes = 0; c.tris = 0; c.meshes = 0; c.wnodes = 0; c.wtris = 0;
+    Cnt c; c.nodes = 0; c.tris = 0; c.meshes = 0; c.wnodes = 0; c.wtris = 0; c.walive = 0;
     bool alive = false;
     f3 o, d, col; uint32_t rng = 0, pixel = 0;
     if (active) {

@@ -67,7 +67,7 @@ struct RtShardDev {
 
 // device counters block (64-bit each); index constants
 enum { RT_CNT_SHADOW = 0, RT_CNT_BOUNCE = 1, RT_CNT_NODES = 2, RT_CNT_TRIS = 3, RT_CNT_MESH = 4,
-       RT_CNT_QUEUE_A = 5, RT_CNT_QUEUE_B = 6, RT_CNT_PRIMARY = 7, RT_CNT_WORK = 8, RT_CNT_WNODE = 9, RT_CNT_WTRI = 10, RT_CNT_N = 11 };
+       RT_CNT_QUEUE_A = 5, RT_CNT_QUEUE_B = 6, RT_CNT_PRIMARY = 7, RT_CNT_WORK = 8, RT_CNT_WNODE = 9, RT_CNT_WTRI = 10, RT_CNT_WALIVE = 11, RT_CNT_N = 12 };
 
 // path-tracing wavefront queue, SoA: 11 dwords per path
 struct RtPathQueue {

@@ -17,4 +17,4 @@ for kind,n,seed in (("field",10000,0x5EED0002),("soup",1389,0x5EED0003)):
         for _ in range(10): ctx.render(flags=(rt.FLAG_SHADOW|lane)|rt.FLAG_TIME_KERNELS)
         k=ctx.counters(); ms=k.kernel_ms/k.kernel_launches
         rays=c.rays_primary+c.rays_shadow
-        print(kind, r, "persist" if lane else "static", "hit %.3f"%(c.rays_shadow/c.rays_primary), "nodes/ray %.1f tris/ray %.2f"%(c.node_visits/rays, c.tri_tests/rays), "ms %.3f Mrays/s %.0f"%(ms, rays/ms/1e3), "util node %.2f tri %.2f witers/wave %d %d"%(c.node_visits/max(1,64*c.wave_node_iters), c.tri_tests/max(1,64*c.wave_tri_iters), c.wave_node_iters/32640, c.wave_tri_iters/32640), flush=True)
+        print(kind, r, "persist" if lane else "static", "hit %.3f"%(c.rays_shadow/c.rays_primary), "nodes/ray %.1f tris/ray %.2f"%(c.node_visits/rays, c.tri_tests/rays), "ms %.3f Mrays/s %.0f"%(ms, rays/ms/1e3), "alive %.2f util node %.2f tri %.2f witers/wave %d %d"%(c.wave_alive_lanes/max(1,64*c.wave_node_iters), c.node_visits/max(1,64*c.wave_node_iters), c.tri_tests/max(1,64*c.wave_tri_iters), c.wave_node_iters/32640, c.wave_tri_iters/32640), flush=True)

@@ -105,6 +105,8 @@ def main():
     ap.add_argument("--mode", default="frames", choices=["frames", "tiles"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--extra-flags", type=lambda v: int(v, 0), default=0,
+                    help="experiments only: OR these RT_FLAG_* bits into every render (e.g. 0x100 = persistent kernel)")
     args = ap.parse_args()
 
     import torch
@@ -145,7 +147,7 @@ def main():
 
     wl = WORKLOADS[args.workload]
     spp, segs = (wl[5], wl[6]) if len(wl) > 5 else (0, 0)
-    flags = rt.FLAG_PATH_TRACE if spp else rt.FLAG_SHADOW
+    flags = (rt.FLAG_PATH_TRACE if spp else rt.FLAG_SHADOW) | args.extra_flags
     shard = dict(shard_rank=rank, shard_count=world, tile_size=64) if tiles else {}
     if spp:
         shard.update(spp=spp, max_segments=segs, seed=1, stream_id=rank)
@@ -228,13 +230,13 @@ def main():
                        "parallelism": ("tiles64-roundrobin+allreduce" if tiles else f"frames-dp{world}")},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                         "kernel": ("k_path_start+k_path_bounce (whole frame)" if spp else "k_primary<false, false>"),
+                         "kernel": ("k_path_start+k_path_bounce (whole frame)" if spp else "k_stream<false>"),
                          "kernel_ms": round(kernel_ms, 4),
                          "algorithmic_bytes_per_launch": int(alg_bytes),
                          "node_visits": int(cnt.node_visits), "tri_tests": int(cnt.tri_tests),
                          "bytes_per_ray": round(alg_bytes / max(rays_step, 1), 1)},
         }
-        if not args.no_cpu_baseline and not spp:
+        if not args.no_cpu_baseline and not spp and world == 1:
             import oracle_py as orc
             view = orc.make_view(m, p, W, H)
             cb, pix, rgba_o, prim_o = cpu_baseline(orc, scene, view, W, H, flags, args.cpu_seconds)

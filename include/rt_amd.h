@@ -86,9 +86,9 @@ int rt_set_view(rt_ctx *ctx, const float world_from_clip[16], const float world_
 #define RT_FLAG_PATH_TRACE    0x0010u  /* progressive path tracing (wgsl:180-202 loop shape) */
 #define RT_FLAG_ACCUMULATE    0x0020u  /* keep the accumulation buffer from earlier frames */
 #define RT_FLAG_TIME_KERNELS  0x0040u  /* bracket kernels with HIP events (rt_get_counters) */
-#define RT_FLAG_PERSISTENT    0x0100u  /* primary/shadow rays: persistent waves with dynamic ray fetch from a
-                                          global work counter instead of one thread per pixel; results are
-                                          identical (measured slower on the bench scenes) */
+#define RT_FLAG_STATIC_GRID   0x0100u  /* primary/shadow rays: one thread per pixel on a hardware-scheduled grid
+                                          (k_primary) instead of the default persistent waves fed from per-XCD
+                                          work queues (k_stream); results are identical (measured slower) */
 #define RT_FLAG_WAVE_TRAVERSAL 0x0080u /* primary/shadow rays: wave-coherent (packet) BVH traversal, one
                                           node fetch per wave, instead of per-lane traversal; results
                                           are identical (measured slower on the bench scenes) */

@@ -1,0 +1,14 @@
+#!/bin/bash
+# Cache-path PMC passes (vector L1 = TCP, texture addresser = TA), one rocprofv3 run each.
+set -u
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+OUT=gpurun_out/pmc_$1
+mkdir -p $OUT
+CMD="python bench.py --steps 5 --warmup 1 --no-cpu-baseline ${BENCH_ARGS:-}"
+run() { name=$1; shift; timeout -s KILL 150 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/$name -- $CMD > $OUT/$name.log 2>&1 || { echo "pass $name failed"; tail -5 $OUT/$name.log; exit 1; }; echo "pass $name ok"; }
+run sq1 SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY
+run sq2 SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_SMEM SQ_THREAD_CYCLES_VALU SQ_LDS_BANK_CONFLICT SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VMEM
+run tcc1 TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_REQ_sum
+run tcp1 TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TOTAL_ACCESSES_sum TCP_PENDING_STALL_CYCLES_sum
+run ta1 TA_BUSY_avr TA_ADDR_STALLED_BY_TC_CYCLES_sum
+run grbm GRBM_GUI_ACTIVE GRBM_COUNT

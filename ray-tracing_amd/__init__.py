@@ -26,7 +26,7 @@ FLAG_PATH_TRACE = 0x0010
 FLAG_ACCUMULATE = 0x0020
 FLAG_TIME_KERNELS = 0x0040
 FLAG_WAVE_TRAVERSAL = 0x0080
-FLAG_PERSISTENT = 0x0100
+FLAG_STATIC_GRID = 0x0100
 
 MISS_PRIM = 0xFFFFFFFF
 

@@ -178,16 +178,20 @@ int rt_create(int device_ordinal, rt_ctx **out) {
     rt_ctx *c = new (std::nothrow) rt_ctx();
     if (!c) return fail(nullptr, RT_ERR_OOM, "rt_create: host allocation failed");
     c->device = device_ordinal;
-    // persistent-kernel geometry: 6 blocks of 256 threads per CU (24 KiB LDS stack each); tunables
-    // can be overridden for experiments through RT_TUNE_BLOCKS_PER_CU / RT_TUNE_REFILL_MIN
+    // persistent-kernel geometry: 8 blocks of 256 threads per CU (16 KiB LDS stack each, <= 64 VGPRs);
+    // the RT_TUNE_* variables are for experiments (tools/ab_traverse.py)
     {
-        uint32_t per_cu = 6, refill = 16;
-        if (const char *e = std::getenv("RT_TUNE_BLOCKS_PER_CU")) per_cu = (uint32_t)std::atoi(e);
-        if (const char *e = std::getenv("RT_TUNE_REFILL_MIN")) refill = (uint32_t)std::atoi(e);
-        if (per_cu < 1 || per_cu > 16) per_cu = 6;
-        if (refill < 1 || refill > 64) refill = 16;
-        c->tune.persist_blocks = (uint32_t)prop.multiProcessorCount * per_cu;
-        c->tune.refill_min = refill;
+        auto env = [](const char *name, uint32_t dflt, uint32_t lo, uint32_t hi) {
+            const char *e = std::getenv(name);
+            if (!e) return dflt;
+            long v = std::atol(e);
+            return (v < (long)lo || v > (long)hi) ? dflt : (uint32_t)v;
+        };
+        c->tune.persist_blocks = (uint32_t)prop.multiProcessorCount * env("RT_TUNE_BLOCKS_PER_CU", 8, 1, 16);
+        c->tune.refill_min = env("RT_TUNE_REFILL_MIN", 64, 1, 64);
+        c->tune.finish_min = env("RT_TUNE_FINISH_MIN", 64, 1, 64);
+        c->tune.vote_node = env("RT_TUNE_VOTE_NODE", 3, 1, 64);
+        c->tune.vote_tri = env("RT_TUNE_VOTE_TRI", 1, 1, 64);
     }
     int rc = RT_OK;
     do {

@@ -82,99 +82,118 @@ struct Hit {
 
 struct Cnt { uint32_t nodes, tris, meshes, wnodes, wtris, walive; };   // w*: wave-level loop trips (first active lane counts)
 
+#define RT_DONE ((int)0x80000001)
+// The lane's stack: entries 0..RT_STACK_LDS-1 in its LDS column, deeper ones in a private array.  Both
+// are reached through address-space-qualified pointers so that the accesses are ds_read/ds_write and
+// scratch_load/scratch_store (a generic pointer -- or a select between the two -- becomes a flat access).
+typedef __attribute__((address_space(3))) int lds_int;
+typedef __attribute__((address_space(5))) int prv_int;
+__device__ __forceinline__ int stack_pop(int &sp, const lds_int *stk, const prv_int *ovf) {
+    if (sp == 0) return RT_DONE;
+    --sp;
+    int v = stk[(sp < RT_STACK_LDS ? sp : RT_STACK_LDS - 1) * RT_BLOCK];
+    if (sp >= RT_STACK_LDS) v = ovf[sp - RT_STACK_LDS];
+    return v;
+}
+__device__ __forceinline__ void stack_push(int &sp, lds_int *stk, prv_int *ovf, int v) {
+    if (sp < RT_STACK_LDS) stk[sp * RT_BLOCK] = v;
+    else if (sp - RT_STACK_LDS < RT_STACK_OVF) ovf[sp - RT_STACK_LDS] = v;
+    ++sp;
+}
+
+
 // ---- BVH traversal (build-side design; reference src/bvh.rs:1 is empty) ----------------------
 // Closest hit with the reference's tie rule restated order-independently: among equal t the
 // lowest position in the (mesh, triangle) loop order wins (ray_tracing.wgsl:164).
 // The per-mesh AABB cull of wgsl:155 is applied to every accepted candidate, so a triangle whose
 // mesh box the ray misses is skipped exactly as the reference's outer loop skips it.
 // ANY: stop at the first accepted hit (shadow rays: hit_triangles(ray).hit).
+//
+// Wave-level shape: every trip of the loop the wave VOTES -- either every lane that holds an inner
+// node takes one node step, or every lane that holds a leaf tests ONE triangle -- so that each
+// instruction issued serves as many lanes as possible; loop control is wave-uniform (ballots).
+// (The first version was a plain per-lane loop; the compiler's structurizer turned it into a node
+// loop that every stack pop left, and a triangle loop that ran with ~10 % of the lanes; written
+// this way the same rays take 1.2-1.4x less time.  vote_node : vote_tri = 3 : 1 measured best: a
+// triangle step as soon as a quarter of the unfinished rays wait at a leaf -- early hits shorten
+// everything that follows.)
+// All lanes that call this must call it together (it counts them with a ballot).
 template <bool ANY, bool COUNT>
-__device__ __forceinline__ void traverse(const RtSceneDev &S, f3 o, f3 d, uint32_t flags, int *stk, Hit &h, Cnt &c) {
+__device__ __forceinline__ void traverse(const RtSceneDev &S, f3 o, f3 d, uint32_t flags, int *stk_generic, Hit &h, Cnt &c,
+                                         uint32_t vote_node = 3u, uint32_t vote_tri = 1u) {
     h.hit = false; h.t = RT_INF; h.u = 0.0f; h.v = 0.0f; h.seq = 0xFFFFFFFFu; h.tri = 0xFFFFFFFFu; h.mesh = 0;
     if (S.n_nodes == 0) return;
     const f3 inv = F3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-    // packed-f32 operands: on gfx950 a plain f32 VALU instruction issues in 4 cycles per wave64 and a
-    // v_pk_* one does two floats per lane in the same 4, so the 12 (plane - o) * inv of a node go as
-    // 6 v_pk_add + 6 v_pk_mul.  The node's 12 floats pair up as (x,y) (z,x) (y,z) (x,y) (z,x) (y,z).
-    const v2f oxy = {o.x, o.y}, ozx = {o.z, o.x}, oyz = {o.y, o.z};
-    const v2f ixy = {inv.x, inv.y}, izx = {inv.z, inv.x}, iyz = {inv.y, inv.z};
-    int ovf[RT_STACK_OVF];
+    lds_int *stk = (lds_int *)stk_generic;
+    int ovf_mem[RT_STACK_OVF];
+    prv_int *ovf = (prv_int *)ovf_mem;
+    const uint32_t n_all = (uint32_t)__builtin_popcountll(__ballot(true));
     int sp = 0;
     int cur = 0;
-    uint32_t last_mesh = 0xFFFFFFFFu;
-    bool last_ok = true;
-    float limit = RT_INF;
-    for (;;) {
-        uint32_t alive_now = COUNT ? (uint32_t)__builtin_popcountll(__ballot(true)) : 0u;   // rays of the wave not finished yet
-        if (cur >= 0) {
-            const float4 *p = reinterpret_cast<const float4 *>(S.nodes + cur);
-            float4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3];
-            if (COUNT) { c.nodes++; if ((threadIdx.x & 63u) == (uint32_t)__builtin_ctzll(__ballot(true))) { c.wnodes++; c.walive += alive_now; } }
-            // slabs of both children; (plane - o) * inv keeps inf/NaN handling conservative
-            v2f a0 = (v2f{q0.x, q0.y} - oxy) * ixy;   // lo0.x lo0.y
-            v2f a1 = (v2f{q0.z, q0.w} - ozx) * izx;   // lo0.z hi0.x
-            v2f a2 = (v2f{q1.x, q1.y} - oyz) * iyz;   // hi0.y hi0.z
-            v2f b0 = (v2f{q1.z, q1.w} - oxy) * ixy;   // lo1.x lo1.y
-            v2f b1 = (v2f{q2.x, q2.y} - ozx) * izx;   // lo1.z hi1.x
-            v2f b2 = (v2f{q2.z, q2.w} - oyz) * iyz;   // hi1.y hi1.z
-            float tmin0 = fmaxf(fmaxf(fminf(a0.x, a1.y), fminf(a0.y, a2.x)), fminf(a1.x, a2.y));
-            float tmin1 = fmaxf(fmaxf(fminf(b0.x, b1.y), fminf(b0.y, b2.x)), fminf(b1.x, b2.y));
-            v2f tmx = {fminf(fminf(fmaxf(a0.x, a1.y), fmaxf(a0.y, a2.x)), fmaxf(a1.x, a2.y)),
-                       fminf(fminf(fmaxf(b0.x, b1.y), fmaxf(b0.y, b2.x)), fmaxf(b1.x, b2.y))};
-            tmx = tmx * v2f{1.0000005f, 1.0000005f};   // robust slab test (2 ulp)
-            float tmax0 = tmx.x, tmax1 = tmx.y;
-            bool h0 = tmin0 <= tmax0 && tmax0 >= 0.0f && tmin0 <= limit;
-            bool h1 = tmin1 <= tmax1 && tmax1 >= 0.0f && tmin1 <= limit;
-            int c0 = __float_as_int(q3.x), c1 = __float_as_int(q3.y);
-            if (h0 && h1) {
+    uint32_t n_done = 0;
+    do {
+        const unsigned long long m_node = __ballot(cur >= 0);
+        const uint32_t n_node = (uint32_t)__builtin_popcountll(m_node);
+        const uint32_t n_leaf = n_all - n_done - n_node;
+        if (n_node * vote_tri >= n_leaf * vote_node) {
+            if (cur >= 0) {
+                const float4 *p = reinterpret_cast<const float4 *>(S.nodes + cur);
+                float4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3];
+                if (COUNT) { c.nodes++; if ((threadIdx.x & 63u) == (uint32_t)__builtin_ctzll(m_node)) { c.wnodes++; c.walive += n_node + n_leaf; } }
+                const float limit = h.t * 1.00001f;   // relaxed bound: near-ties are still visited, seq decides
+                // slabs of both children; (plane - o) * inv keeps inf/NaN handling conservative
+                float ax0 = (q0.x - o.x) * inv.x, ax1 = (q0.w - o.x) * inv.x;
+                float ay0 = (q0.y - o.y) * inv.y, ay1 = (q1.x - o.y) * inv.y;
+                float az0 = (q0.z - o.z) * inv.z, az1 = (q1.y - o.z) * inv.z;
+                float bx0 = (q1.z - o.x) * inv.x, bx1 = (q2.y - o.x) * inv.x;
+                float by0 = (q1.w - o.y) * inv.y, by1 = (q2.z - o.y) * inv.y;
+                float bz0 = (q2.x - o.z) * inv.z, bz1 = (q2.w - o.z) * inv.z;
+                float tmin0 = fmaxf(fmaxf(fminf(ax0, ax1), fminf(ay0, ay1)), fminf(az0, az1));
+                float tmax0 = fminf(fminf(fmaxf(ax0, ax1), fmaxf(ay0, ay1)), fmaxf(az0, az1));
+                float tmin1 = fmaxf(fmaxf(fminf(bx0, bx1), fminf(by0, by1)), fminf(bz0, bz1));
+                float tmax1 = fminf(fminf(fmaxf(bx0, bx1), fmaxf(by0, by1)), fmaxf(bz0, bz1));
+                tmax0 *= 1.0000005f; tmax1 *= 1.0000005f;   // robust slab test (2 ulp)
+                bool h0 = tmin0 <= tmax0 && tmax0 >= 0.0f && tmin0 <= limit;
+                bool h1 = tmin1 <= tmax1 && tmax1 >= 0.0f && tmin1 <= limit;
+                int c0 = __float_as_int(q3.x), c1 = __float_as_int(q3.y);
+                bool both = h0 && h1;
                 bool swap = tmin1 < tmin0;
-                int nearc = swap ? c1 : c0, farc = swap ? c0 : c1;
-                if (sp < RT_STACK_LDS) stk[sp * RT_BLOCK] = farc;
-                else if (sp - RT_STACK_LDS < RT_STACK_OVF) ovf[sp - RT_STACK_LDS] = farc;
-                ++sp;
-                cur = nearc;
-                continue;
+                if (both) stack_push(sp, stk, ovf, swap ? c0 : c1);
+                if (h0 || h1) cur = (both ? swap : h1) ? c1 : c0;
+                else cur = stack_pop(sp, stk, ovf);
             }
-            if (h0) { cur = c0; continue; }
-            if (h1) { cur = c1; continue; }
-        } else if (cur != RT_CHILD_NONE) {
-            uint32_t code = (uint32_t)(~cur);
-            uint32_t first = code >> 3, n = (code & 7u) + 1u;
-            for (uint32_t k = 0; k < n; ++k) {
-                const float4 *r = reinterpret_cast<const float4 *>(S.recs + first + k);
-                float4 r0 = r[0], r1 = r[1], r2 = r[2];
-                if (COUNT) { c.tris++; if ((threadIdx.x & 63u) == (uint32_t)__builtin_ctzll(__ballot(true))) c.wtris++; }
-                float dst, u, v;
-                bool ok = ray_tri(o, d, F3(r0.x, r0.y, r0.z), F3(r0.w, r1.x, r1.y), F3(r1.z, r1.w, r2.x), dst, u, v);
-                uint32_t seq = __float_as_uint(r2.w);
-                ok = ok && (dst < h.t || (dst == h.t && seq < h.seq));
-                if (ok) {
+        } else {
+            if (cur < 0 && cur != RT_DONE) {
+                if (cur == RT_CHILD_NONE) cur = stack_pop(sp, stk, ovf);
+                else {
+                    uint32_t code = (uint32_t)(~cur);
+                    uint32_t first = code >> 3, left = code & 7u;
+                    const float4 *r = reinterpret_cast<const float4 *>(S.recs + first);
+                    float4 r0 = r[0], r1 = r[1], r2 = r[2];
+                    if (COUNT) { c.tris++; if ((threadIdx.x & 63u) == (uint32_t)__builtin_ctzll(__ballot(true))) c.wtris++; }
+                    float dst, u, v;
+                    bool ok = ray_tri(o, d, F3(r0.x, r0.y, r0.z), F3(r0.w, r1.x, r1.y), F3(r1.z, r1.w, r2.x), dst, u, v);
+                    uint32_t seq = __float_as_uint(r2.w);
+                    ok = ok && (dst < h.t || (dst == h.t && seq < h.seq));
                     uint32_t mesh = __float_as_uint(r2.z);
-                    if (!(flags & RT_FLAG_NO_MESH_CULL)) {
-                        if (mesh != last_mesh) {
-                            const float4 *mp = reinterpret_cast<const float4 *>(S.meshes + mesh);
-                            float4 m1 = mp[1], m2 = mp[2];
-                            last_ok = ray_aabb_ref(o, inv, F3(m1.x, m1.y, m1.z), F3(m2.x, m2.y, m2.z));
-                            last_mesh = mesh;
-                            if (COUNT) c.meshes++;
-                        }
-                        ok = last_ok;
+                    if (ok && !(flags & RT_FLAG_NO_MESH_CULL)) {   // per-mesh AABB cull of wgsl:155
+                        const float4 *mp = reinterpret_cast<const float4 *>(S.meshes + mesh);
+                        float4 m1 = mp[1], m2 = mp[2];
+                        ok = ray_aabb_ref(o, inv, F3(m1.x, m1.y, m1.z), F3(m2.x, m2.y, m2.z));
+                        if (COUNT) c.meshes++;
                     }
                     if (ok) {
                         h.hit = true; h.t = dst; h.u = u; h.v = v; h.seq = seq;
                         h.tri = __float_as_uint(r2.y); h.mesh = mesh;
-                        // boxes are culled against a slightly relaxed bound so that a near-tie
-                        // (shared edge, coincident faces) is still visited and resolved by seq
-                        limit = dst * 1.00001f;
-                        if (ANY) return;
                     }
+                    if (ok && ANY) cur = RT_DONE;
+                    else if (left == 0u) cur = stack_pop(sp, stk, ovf);
+                    else cur = ~(int)(((first + 1u) << 3) | (left - 1u));
                 }
             }
         }
-        if (sp == 0) break;
-        --sp;
-        cur = sp < RT_STACK_LDS ? stk[sp * RT_BLOCK] : ovf[sp - RT_STACK_LDS];
-    }
+        n_done = (uint32_t)__builtin_popcountll(__ballot(cur == RT_DONE));
+    } while (n_done != n_all);
 }
 
 
@@ -442,204 +461,230 @@ __global__ __launch_bounds__(RT_BLOCK, RT_MIN_WAVES) void k_primary(RtSceneDev S
 }
 
 
-// ---- persistent primary(+shadow) kernel with dynamic ray fetch ---------------------------------------
-// Measured on the per-pixel-per-thread kernel above: only ~31 % of the lanes are active in an
-// average VALU instruction -- a wave runs until its LONGEST ray is done, and the lanes whose
-// primary ray missed idle through the whole shadow phase.  Here waves are persistent: a lane
-// whose ray has finished (primary AND shadow) becomes idle, and as soon as `refill_min` lanes of
-// a wave are idle they take the next pixels from one global work counter (one atomic per wave
-// refill).  Work is handed out in 8x8-tile order, so the rays a wave holds stay coherent.
-// Per-pixel results do not depend on the schedule: same arithmetic, same closest-hit rule.
-// Per-lane state is kept small (occupancy): the best hit is (t, seq, record index); u, v and the
-// mesh are recomputed from the record when the ray ends (same inputs, same bits).
-#define RT_DONE ((int)0x80000001)
-struct LaneRay {
-    f3 o, d, inv;
-    float t;              // best hit distance so far (inf: none)
-    uint32_t seq, rec;    // its loop-order position and its record index
-    int cur, sp;
-};
-
-__device__ __forceinline__ void lr_start(const RtSceneDev &S, LaneRay &r, f3 o, f3 d) {
-    r.o = o; r.d = d;
-    r.inv = F3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-    r.t = RT_INF; r.seq = 0xFFFFFFFFu; r.rec = 0xFFFFFFFFu;
-    r.cur = S.n_nodes ? 0 : RT_DONE;
-    r.sp = 0;
+// ---- k_stream: persistent waves, per-XCD work queues, phase voting, batched hand-over ---------------
+// What RT_FLAG_COUNTERS shows for k_primary on the 7.2 M-triangle bench scene: a wave lives as long as
+// its LONGEST ray, so 46 % of its node-loop trips run with <= 8 of the 64 rays still unfinished (58 %
+// with <= 16), its triangle loop runs with ~10 % of the lanes, and every lane waits at the end of the
+// primary phase for the wave's last primary ray before any shadow ray starts.  Here
+//   * waves are persistent; a lane is a little state machine (idle / primary ray / shadow ray), a lane
+//     whose primary ray ends starts its shadow ray without waiting for the wave;
+//   * every trip of the main loop the wave VOTES: either every lane that holds an inner node takes one
+//     node step, or every lane that holds a leaf tests ONE triangle -- whichever serves more lanes per
+//     instruction issued (vote weights: RtTune).  All loop control is wave-uniform (ballots), nothing is left to the
+//     compiler's structurizer (it re-shapes k_primary's loop from one build to the next);
+//   * ended rays are handed over in batches (shade + write + start the shadow ray + take new pixels),
+//     so the divergent finishing code runs for many lanes at once;
+//   * work comes from EIGHT queues, one per XCD (read from HW_REG_XCC_ID): queue x holds the 64x64
+//     shard tiles k with k % 8 == x as 16x16-pixel regions; a wave owns a region until its 256 pixels
+//     are handed out (one atomic per 256 pixels; one queue head would saturate at ~88 dequeues/us:
+//     MI355X guide, row 'dequeue').  A wave whose home queue is empty steals from the next ones.
+//     refill_min = 64 hands a wave one whole 8x8 pixel block at a time (rays stay in lockstep, the
+//     vector L1 serves most node fetches); smaller values refill single lanes (fewer idle lanes, but
+//     desynchronised rays: measured 2.7x more L2 requests and slower on BVHs beyond the L2);
+//     Measured and dropped: PARKING a wave's last <= 8 rays for a second launch that packs the stragglers of
+//     all waves (fewer loop trips, but that launch runs few, long, incoherent rays: 1.47 vs 1.33 ms), and
+//     handing a block's four waves the four 8x8 blocks of one 16x16 quad (coarser work units balance worse:
+//     1.9 vs 1.33 ms at 1080p, where a wave only sees ~4 regions).
+// Per-pixel results do not depend on any of this: same arithmetic, same closest-hit rule.
+__device__ __forceinline__ uint32_t xcc_id() {
+    uint32_t v;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(v));
+    return v & 7u;
 }
-__device__ __forceinline__ int lr_pop(LaneRay &r, const int *stk, const int *ovf) {
-    if (r.sp == 0) return RT_DONE;
-    --r.sp;
-    return r.sp < RT_STACK_LDS ? stk[r.sp * RT_BLOCK] : ovf[r.sp - RT_STACK_LDS];
-}
-
-// Advance one ray: descend inner nodes until a leaf (or the end), then test that leaf.
-// while-while shape: lanes that reached a leaf wait for the wave's node loop, then all leaves of
-// the wave are processed together.  On return r.cur == RT_DONE iff the ray is finished.
-template <bool COUNT>
-__device__ __forceinline__ void lr_advance(const RtSceneDev &S, uint32_t flags, LaneRay &r, bool any, bool active,
-                                           int *stk, int *ovf, Cnt &c) {
-    const float limit = r.t * 1.00001f;   // relaxed bound: near-ties are still visited, seq decides
-    while (active && r.cur >= 0) {
-        const float4 *p = reinterpret_cast<const float4 *>(S.nodes + r.cur);
-        float4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3];
-        if (COUNT) c.nodes++;
-        const f3 o = r.o, inv = r.inv;
-        float ax0 = (q0.x - o.x) * inv.x, ax1 = (q0.w - o.x) * inv.x;
-        float ay0 = (q0.y - o.y) * inv.y, ay1 = (q1.x - o.y) * inv.y;
-        float az0 = (q0.z - o.z) * inv.z, az1 = (q1.y - o.z) * inv.z;
-        float bx0 = (q1.z - o.x) * inv.x, bx1 = (q2.y - o.x) * inv.x;
-        float by0 = (q1.w - o.y) * inv.y, by1 = (q2.z - o.y) * inv.y;
-        float bz0 = (q2.x - o.z) * inv.z, bz1 = (q2.w - o.z) * inv.z;
-        float tmin0 = fmaxf(fmaxf(fminf(ax0, ax1), fminf(ay0, ay1)), fminf(az0, az1));
-        float tmax0 = fminf(fminf(fmaxf(ax0, ax1), fmaxf(ay0, ay1)), fmaxf(az0, az1));
-        float tmin1 = fmaxf(fmaxf(fminf(bx0, bx1), fminf(by0, by1)), fminf(bz0, bz1));
-        float tmax1 = fminf(fminf(fmaxf(bx0, bx1), fmaxf(by0, by1)), fmaxf(bz0, bz1));
-        tmax0 *= 1.0000005f; tmax1 *= 1.0000005f;
-        bool h0 = tmin0 <= tmax0 && tmax0 >= 0.0f && tmin0 <= limit;
-        bool h1 = tmin1 <= tmax1 && tmax1 >= 0.0f && tmin1 <= limit;
-        int c0 = __float_as_int(q3.x), c1 = __float_as_int(q3.y);
-        if (h0 && h1) {
-            bool swap = tmin1 < tmin0;
-            int farc = swap ? c0 : c1;
-            if (r.sp < RT_STACK_LDS) stk[r.sp * RT_BLOCK] = farc;
-            else if (r.sp - RT_STACK_LDS < RT_STACK_OVF) ovf[r.sp - RT_STACK_LDS] = farc;
-            ++r.sp;
-            r.cur = swap ? c1 : c0;
-        } else if (h0) r.cur = c0;
-        else if (h1) r.cur = c1;
-        else r.cur = lr_pop(r, stk, ovf);
-    }
-    if (active && r.cur != RT_DONE) {
-        if (r.cur != RT_CHILD_NONE) {
-            uint32_t code = (uint32_t)(~r.cur);
-            uint32_t first = code >> 3, n = (code & 7u) + 1u;
-            for (uint32_t k = 0; k < n; ++k) {
-                const float4 *t = reinterpret_cast<const float4 *>(S.recs + first + k);
-                float4 r0 = t[0], r1 = t[1], r2 = t[2];
-                if (COUNT) c.tris++;
-                float dst, u, v;
-                bool ok = ray_tri(r.o, r.d, F3(r0.x, r0.y, r0.z), F3(r0.w, r1.x, r1.y), F3(r1.z, r1.w, r2.x), dst, u, v);
-                uint32_t seq = __float_as_uint(r2.w);
-                ok = ok && (dst < r.t || (dst == r.t && seq < r.seq));
-                if (ok && !(flags & RT_FLAG_NO_MESH_CULL)) {   // per-mesh AABB cull of wgsl:155
-                    const float4 *mp = reinterpret_cast<const float4 *>(S.meshes + __float_as_uint(r2.z));
-                    float4 m1 = mp[1], m2 = mp[2];
-                    ok = ray_aabb_ref(r.o, r.inv, F3(m1.x, m1.y, m1.z), F3(m2.x, m2.y, m2.z));
-                    if (COUNT) c.meshes++;
-                }
-                if (ok) {
-                    r.t = dst; r.seq = seq; r.rec = first + k;
-                    if (any) { r.cur = RT_DONE; return; }
-                }
-            }
-        }
-        r.cur = lr_pop(r, stk, ovf);
-    }
-}
-
-// point, interpolated normal (ray_tracing.wgsl:137-138) and material of the ray's best hit
-__device__ __forceinline__ void lr_finish(const RtSceneDev &S, const LaneRay &r, f3 &point, f3 &normal,
-                                          uint32_t &material, uint32_t &tri) {
-    const float4 *t = reinterpret_cast<const float4 *>(S.recs + r.rec);
-    float4 r0 = t[0], r1 = t[1], r2 = t[2];
-    float dst, u, v;
-    (void)ray_tri(r.o, r.d, F3(r0.x, r0.y, r0.z), F3(r0.w, r1.x, r1.y), F3(r1.z, r1.w, r2.x), dst, u, v);
-    Hit h;
-    h.hit = true; h.t = dst; h.u = u; h.v = v; h.seq = r.seq;
-    h.tri = __float_as_uint(r2.y); h.mesh = __float_as_uint(r2.z);
-    tri = h.tri;
-    finish_hit(S, r.o, r.d, h, point, normal, material);
-}
-
-// work index -> pixel: 64 consecutive indices = one 8x8 tile; tiles row-major inside a shard tile
-__device__ __forceinline__ bool pixel_of_index(const RtViewDev &V, const RtShardDev &sh, uint32_t i, uint32_t &px,
-                                               uint32_t &py) {
-    uint32_t sub8 = sh.tile >> 3;
-    uint32_t per_tile = sub8 * sub8;
-    uint32_t t8 = i >> 6, w = i & 63u;
-    uint32_t k = t8 / per_tile, s = t8 % per_tile;
+// Region r of queue x, pixel w of the region -> screen pixel.  A region is one 8x8 pixel block; a
+// queue lists the blocks of its tiles so that four consecutive regions form a 16x16 quad (waves that
+// dequeue one after the other work next to each other, as the blocks of k_primary's grid do; with
+// 16x16 regions four times as much screen -- and BVH -- was in flight per XCD and the L2 missed more).
+#define RT_REGION_PX 64u
+__device__ __forceinline__ bool pixel_of_region(const RtViewDev &V, const RtShardDev &sh, uint32_t x, uint32_t r,
+                                                uint32_t w, uint32_t &px, uint32_t &py) {
+    uint32_t sub = sh.tile >> 4;                 // 16x16 quads per tile edge
+    uint32_t rpt = sub * sub * 4u;               // regions per tile
+    uint32_t k = (r / rpt) * 8u + x, rr = r % rpt;
     uint32_t g = sh.rank + k * (sh.count ? sh.count : 1u);
     uint32_t gx = g % sh.tiles_x, gy = g / sh.tiles_x;
-    uint32_t x = gx * sh.tile + (s % sub8) * 8u + (w & 7u);
-    uint32_t y = gy * sh.tile + (s / sub8) * 8u + (w >> 3);
-    px = V.vx + x; py = V.vy + y;
-    return x < V.vw && y < V.vh;
+    uint32_t quad = rr >> 2, b = rr & 3u;
+    uint32_t xx = gx * sh.tile + (quad % sub) * 16u + (b & 1u) * 8u + (w & 7u);
+    uint32_t yy = gy * sh.tile + (quad / sub) * 16u + (b >> 1) * 8u + (w >> 3);
+    px = V.vx + xx; py = V.vy + yy;
+    return xx < V.vw && yy < V.vh;
 }
 
-#ifndef RT_PERSIST_MIN_WAVES
-#define RT_PERSIST_MIN_WAVES 6
-#endif
 template <bool COUNT>
-__global__ __launch_bounds__(RT_BLOCK, RT_PERSIST_MIN_WAVES) void k_primary_persist(
-    RtSceneDev S, RtViewDev V, RtShardDev sh, uint32_t total, uint32_t flags, uint32_t refill_min,
-    float4 *__restrict__ rgba, uint32_t *__restrict__ prim, float *__restrict__ tout,
-    unsigned long long *__restrict__ counters) {
+__global__ __launch_bounds__(RT_BLOCK, RT_MIN_WAVES) void k_stream(
+    RtSceneDev S_, RtViewDev V_, RtShardDev sh_, uint32_t flags, uint32_t refill_min, uint32_t finish_min,
+    uint32_t vote_node, uint32_t vote_tri, float4 *__restrict__ rgba, uint32_t *__restrict__ prim,
+    float *__restrict__ tout, unsigned long long *__restrict__ counters) {
     __shared__ int s_stack[RT_STACK_LDS * RT_BLOCK];
-    int *stk = s_stack + threadIdx.x;
-    int ovf[RT_STACK_OVF];
+    // what only the hand-over code reads lives in LDS, not in ~60 SGPRs that the hot loop would spill
+    __shared__ RtSceneDev S;
+    __shared__ RtViewDev V;
+    __shared__ RtShardDev sh;
+    if (threadIdx.x == 0) { S = S_; V = V_; sh = sh_; }
+    __syncthreads();
+    lds_int *stk = (lds_int *)(s_stack + threadIdx.x);
+    int ovf_mem[RT_STACK_OVF];
+    prv_int *ovf = (prv_int *)ovf_mem;
+    const RtBvhNode *const nodes = S_.nodes;
+    const RtTriRecord *const recs = S_.recs;
+    const rt_mesh_info *const meshes = S_.meshes;
     const uint32_t lane = threadIdx.x & 63u;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    const uint32_t home = xcc_id();
+    unsigned long long *heads = counters + RT_CNT_HEADS;
+    // wave-uniform work-source state
+    uint32_t reg_q = 0, reg_r = 0, reg_next = RT_REGION_PX;  // the wave's region and its next pixel
+    uint32_t qoff = 0u;                                     // queues found empty so far (8 = all)
     Cnt c; c.nodes = 0; c.tris = 0; c.meshes = 0; c.wnodes = 0; c.wtris = 0; c.walive = 0;
     uint32_t n_primary = 0, n_shadow = 0;
+    // per-lane ray
+    f3 o = F3(0.0f, 0.0f, 0.0f), d = F3(0.0f, 0.0f, 1.0f), inv = F3(0.0f, 0.0f, 1.0f);
+    float t = RT_INF, hu = 0.0f, hv = 0.0f;
+    uint32_t seq = 0xFFFFFFFFu, rec = 0xFFFFFFFFu;
+    int cur = RT_DONE, sp = 0;
     int state = 0;                 // 0 idle, 1 primary ray, 2 shadow ray
-    bool exhausted = false;        // wave-uniform: the work counter has run past `total`
-    LaneRay r;
-    lr_start(S, r, F3(0.0f, 0.0f, 0.0f), F3(0.0f, 0.0f, 1.0f));
-    r.cur = RT_DONE;
     uint32_t idx = 0;
     for (;;) {
-        unsigned long long idle = __ballot(state == 0);
-        uint32_t n_idle = (uint32_t)__builtin_popcountll(idle);
-        if (!exhausted && (n_idle >= refill_min || n_idle == 64u)) {
-            uint32_t base = 0;
-            int leader = __builtin_ctzll(idle);
-            if ((int)lane == leader) base = (uint32_t)atomicAdd(counters + RT_CNT_WORK, (unsigned long long)n_idle);
-            base = __shfl(base, leader);
-            if (state == 0) {
-                uint32_t my = base + (uint32_t)__builtin_popcountll(idle & ((1ull << lane) - 1ull));
-                uint32_t px, py;
-                if (my < total && pixel_of_index(V, sh, my, px, py)) {
-                    f3 o, d;
-                    ray_gen(V, px, py, o, d);
-                    lr_start(S, r, o, d);
-                    idx = py * V.width + px;
-                    state = 1;
-                    ++n_primary;
+        // ================= service: runs when the hot loop below asks for it =================================
+        // ---- 1. finish ended rays (shade, write, start the shadow ray) -----------------------------------------
+        if (cur == RT_DONE && state == 1) {
+            float4 out = make_float4(0.0f, 0.0f, 0.0f, 0.0f);      // miss: vec4(0) (wgsl:210)
+            uint32_t out_prim = 0xFFFFFFFFu; float out_t = 0.0f;
+            state = 0;
+            if (rec != 0xFFFFFFFFu) {
+                float4 r2 = reinterpret_cast<const float4 *>(recs + rec)[2];
+                Hit h;
+                h.hit = true; h.t = t; h.u = hu; h.v = hv; h.seq = seq;
+                h.tri = __float_as_uint(r2.y); h.mesh = __float_as_uint(r2.z);
+                f3 point, normal; uint32_t material;
+                finish_hit(S, o, d, h, point, normal, material);
+                out = shade_hit(S, normal, material);
+                out_prim = h.tri; out_t = t;
+                if (flags & RT_FLAG_SHADOW) {
+                    o = add(point, scl(normal, 1e-3f)); d = F3(0.0f, 1.0f, 0.0f);
+                    inv = F3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+                    t = RT_INF; seq = 0xFFFFFFFFu; rec = 0xFFFFFFFFu;
+                    cur = 0; sp = 0;
+                    state = 2;
+                    ++n_shadow;
                 }
             }
-            exhausted = base + n_idle >= total;
+            // the unshadowed value is stored now; an occluded shadow ray scales it in place later
+            rgba[idx] = out; prim[idx] = out_prim; tout[idx] = out_t;
+        } else if (cur == RT_DONE && state == 2) {
+            if (rec != 0xFFFFFFFFu) {
+                float4 out = rgba[idx];
+                rgba[idx] = make_float4(out.x * 0.25f, out.y * 0.25f, out.z * 0.25f, out.w * 0.25f);
+            }
+            state = 0;
         }
-        if (__ballot(state != 0) == 0ull) {
-            if (exhausted) break;
-            continue;
-        }
-        lr_advance<COUNT>(S, flags, r, state == 2, state != 0, stk, ovf, c);
-        if (state != 0 && r.cur == RT_DONE) {
-            if (state == 1) {
-                float4 out = make_float4(0.0f, 0.0f, 0.0f, 0.0f);      // miss: vec4(0) (wgsl:210)
-                uint32_t out_prim = 0xFFFFFFFFu; float out_t = 0.0f;
-                state = 0;
-                if (r.rec != 0xFFFFFFFFu) {
-                    f3 point, normal; uint32_t material;
-                    lr_finish(S, r, point, normal, material, out_prim);
-                    out = shade_hit(S, normal, material);
-                    out_t = r.t;
-                    if (flags & RT_FLAG_SHADOW) {
-                        lr_start(S, r, add(point, scl(normal, 1e-3f)), F3(0.0f, 1.0f, 0.0f));
-                        state = 2;
-                        ++n_shadow;
+        // ---- 2. idle lanes take new work -------------------------------------------------------------------------
+        unsigned long long idle = __ballot(state == 0);
+        {
+            // the wave's region first; a used-up region is replaced from the XCD's queue (one atomic per 64
+            // pixels), an empty queue by the next XCD's
+            const bool all_idle = idle == ~0ull;
+            const uint32_t rpt = (sh.tile >> 4) * (sh.tile >> 4) * 4u;   // 8x8 regions per shard tile
+            while (idle && ((uint32_t)__builtin_popcountll(idle) >= refill_min || all_idle)) {
+                if (reg_next >= RT_REGION_PX) {               // wave-uniform
+                    if (qoff >= 8u) break;
+                    const uint32_t q = (home + qoff) & 7u;
+                    const uint32_t n_tiles_q = sh.n_owned > q ? (sh.n_owned - q + 7u) / 8u : 0u;
+                    const uint32_t len = n_tiles_q * rpt;
+                    uint32_t r = len;
+                    if (len != 0u) {
+                        if (lane == 0u) r = (uint32_t)atomicAdd(heads + q * 16u, 1ull);
+                        r = (uint32_t)__builtin_amdgcn_readfirstlane((int)r);
+                    }
+                    if (r >= len) { ++qoff; continue; }       // this queue is empty: next one
+                    reg_q = q; reg_r = r; reg_next = 0u;
+                }
+                if (state == 0) {
+                    uint32_t w = reg_next + (uint32_t)__builtin_popcountll(idle & below);
+                    uint32_t px, py;
+                    if (w < RT_REGION_PX && pixel_of_region(V, sh, reg_q, reg_r, w, px, py)) {
+                        ray_gen(V, px, py, o, d);
+                        inv = F3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+                        t = RT_INF; seq = 0xFFFFFFFFu; rec = 0xFFFFFFFFu;
+                        cur = S.n_nodes ? 0 : RT_DONE; sp = 0;
+                        idx = py * V.width + px;
+                        state = 1;
+                        ++n_primary;
                     }
                 }
-                // the unshadowed value is stored now; an occluded shadow ray scales it in place later
-                rgba[idx] = out; prim[idx] = out_prim; tout[idx] = out_t;
-            } else {
-                if (r.rec != 0xFFFFFFFFu) {
-                    float4 out = rgba[idx];
-                    rgba[idx] = make_float4(out.x * 0.25f, out.y * 0.25f, out.z * 0.25f, out.w * 0.25f);
-                }
-                state = 0;
+                reg_next += (uint32_t)__builtin_popcountll(idle);   // pixels outside the image are skipped
+                idle = __ballot(state == 0);
             }
+            if (idle == ~0ull && qoff >= 8u && reg_next >= RT_REGION_PX) break;   // nothing in flight, nothing left
         }
+        if (__ballot(cur != RT_DONE) == 0ull) continue;   // only ended rays (e.g. an empty scene): service again
+        // ================= hot loop: one voted step per trip, until the wave needs service ========================
+        const bool more = qoff < 8u || reg_next < RT_REGION_PX;
+        const bool any = state == 2;
+        // idle lanes stay idle inside the hot loop, so ended-but-unfinished rays = done - idle: two ballots a trip
+        const uint32_t n_idle = (uint32_t)__builtin_popcountll(__ballot(state == 0));
+        uint32_t n_done = (uint32_t)__builtin_popcountll(__ballot(cur == RT_DONE)), n_pend, n_live;
+        do {
+            // ---- vote: one node step or one triangle step for the whole wave -----------------------------------
+            const unsigned long long m_node = __ballot(cur >= 0);
+            const uint32_t n_node = (uint32_t)__builtin_popcountll(m_node);
+            const uint32_t n_leaf = 64u - n_done - n_node;
+            if (n_node * vote_tri >= n_leaf * vote_node) {
+                if (cur >= 0) {
+                    const float4 *p = reinterpret_cast<const float4 *>(nodes + cur);
+                    float4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3];
+                    if (COUNT) { c.nodes++; if (lane == (uint32_t)__builtin_ctzll(m_node)) { c.wnodes++; c.walive += n_node + n_leaf; } }
+                    const float limit = t * 1.00001f;   // relaxed bound: near-ties are still visited, seq decides
+                    float ax0 = (q0.x - o.x) * inv.x, ax1 = (q0.w - o.x) * inv.x;
+                    float ay0 = (q0.y - o.y) * inv.y, ay1 = (q1.x - o.y) * inv.y;
+                    float az0 = (q0.z - o.z) * inv.z, az1 = (q1.y - o.z) * inv.z;
+                    float bx0 = (q1.z - o.x) * inv.x, bx1 = (q2.y - o.x) * inv.x;
+                    float by0 = (q1.w - o.y) * inv.y, by1 = (q2.z - o.y) * inv.y;
+                    float bz0 = (q2.x - o.z) * inv.z, bz1 = (q2.w - o.z) * inv.z;
+                    float tmin0 = fmaxf(fmaxf(fminf(ax0, ax1), fminf(ay0, ay1)), fminf(az0, az1));
+                    float tmax0 = fminf(fminf(fmaxf(ax0, ax1), fmaxf(ay0, ay1)), fmaxf(az0, az1));
+                    float tmin1 = fmaxf(fmaxf(fminf(bx0, bx1), fminf(by0, by1)), fminf(bz0, bz1));
+                    float tmax1 = fminf(fminf(fmaxf(bx0, bx1), fmaxf(by0, by1)), fmaxf(bz0, bz1));
+                    tmax0 *= 1.0000005f; tmax1 *= 1.0000005f;   // robust slab test (2 ulp)
+                    bool h0 = tmin0 <= tmax0 && tmax0 >= 0.0f && tmin0 <= limit;
+                    bool h1 = tmin1 <= tmax1 && tmax1 >= 0.0f && tmin1 <= limit;
+                    int c0 = __float_as_int(q3.x), c1 = __float_as_int(q3.y);
+                    bool both = h0 && h1;
+                    bool swap = tmin1 < tmin0;
+                    if (both) stack_push(sp, stk, ovf, swap ? c0 : c1);
+                    if (h0 || h1) cur = (both ? swap : h1) ? c1 : c0;
+                    else cur = stack_pop(sp, stk, ovf);
+                }
+            } else {
+                if (cur < 0 && cur != RT_DONE) {
+                    if (cur == RT_CHILD_NONE) cur = stack_pop(sp, stk, ovf);
+                    else {
+                        uint32_t code = (uint32_t)(~cur);
+                        uint32_t first = code >> 3, left = code & 7u;
+                        const float4 *r = reinterpret_cast<const float4 *>(recs + first);
+                        float4 r0 = r[0], r1 = r[1], r2 = r[2];
+                        if (COUNT) { c.tris++; if (lane == (uint32_t)__builtin_ctzll(__ballot(true))) c.wtris++; }
+                        float dst, u, v;
+                        bool ok = ray_tri(o, d, F3(r0.x, r0.y, r0.z), F3(r0.w, r1.x, r1.y), F3(r1.z, r1.w, r2.x), dst, u, v);
+                        uint32_t sq = __float_as_uint(r2.w);
+                        ok = ok && (dst < t || (dst == t && sq < seq));
+                        if (ok && !(flags & RT_FLAG_NO_MESH_CULL)) {   // per-mesh AABB cull of wgsl:155
+                            const float4 *mp = reinterpret_cast<const float4 *>(meshes + __float_as_uint(r2.z));
+                            float4 m1 = mp[1], m2 = mp[2];
+                            ok = ray_aabb_ref(o, inv, F3(m1.x, m1.y, m1.z), F3(m2.x, m2.y, m2.z));
+                            if (COUNT) c.meshes++;
+                        }
+                        if (ok) { t = dst; seq = sq; rec = first; hu = u; hv = v; }
+                        if (ok && any) cur = RT_DONE;                        // shadow ray: any hit answers it
+                        else if (left == 0u) cur = stack_pop(sp, stk, ovf);
+                        else cur = ~(int)(((first + 1u) << 3) | (left - 1u));
+                    }
+                }
+            }
+            n_done = (uint32_t)__builtin_popcountll(__ballot(cur == RT_DONE));
+            n_pend = n_done - n_idle;
+            n_live = 64u - n_done;
+        } while (!(n_live == 0u || n_pend >= finish_min || (more && n_done >= refill_min)));
     }
     wave_sum(counters + RT_CNT_PRIMARY, n_primary);
     wave_sum(counters + RT_CNT_SHADOW, n_shadow);
@@ -647,6 +692,9 @@ __global__ __launch_bounds__(RT_BLOCK, RT_PERSIST_MIN_WAVES) void k_primary_pers
         wave_sum(counters + RT_CNT_NODES, c.nodes);
         wave_sum(counters + RT_CNT_TRIS, c.tris);
         wave_sum(counters + RT_CNT_MESH, c.meshes);
+        wave_sum(counters + RT_CNT_WNODE, c.wnodes);
+        wave_sum(counters + RT_CNT_WTRI, c.wtris);
+        wave_sum(counters + RT_CNT_WALIVE, c.walive);
     }
 }
 
@@ -882,17 +930,14 @@ hipError_t rtk_launch_primary(hipStream_t st, const RtSceneDev &S, const RtViewD
     if (nb == 0) return hipSuccess;
     bool count = (flags & RT_FLAG_COUNTERS) != 0;
     bool packet = (flags & RT_FLAG_WAVE_TRAVERSAL) && !(flags & RT_FLAG_BRUTE_FORCE);
-    if (!packet && (flags & RT_FLAG_PERSISTENT) && !(flags & RT_FLAG_BRUTE_FORCE)) {
-        // persistent kernel: a grid that fills the chip once; blocks that start late find the work
-        // counter exhausted and exit, so no residency assumption is made
-        uint32_t total = sh.n_owned * sh.tile * sh.tile;
-        uint32_t need = (total + RT_BLOCK - 1) / RT_BLOCK;
+    if (!packet && !(flags & RT_FLAG_STATIC_GRID) && !(flags & RT_FLAG_BRUTE_FORCE)) {
+        // persistent kernel: a grid that fills the chip once; blocks that start late find the queues
+        // empty and exit, so no residency assumption is made
+        uint32_t need = (sh.n_owned * sh.tile * sh.tile + RT_BLOCK - 1) / RT_BLOCK;
         uint32_t grid = tune.persist_blocks < need ? tune.persist_blocks : need;
         if (grid == 0) return hipSuccess;
-        if (count)
-            hipLaunchKernelGGL((k_primary_persist<true>), dim3(grid), dim3(RT_BLOCK), 0, st, S, V, sh, total, flags, tune.refill_min, (float4 *)rgba, prim, t, counters);
-        else
-            hipLaunchKernelGGL((k_primary_persist<false>), dim3(grid), dim3(RT_BLOCK), 0, st, S, V, sh, total, flags, tune.refill_min, (float4 *)rgba, prim, t, counters);
+        if (count) hipLaunchKernelGGL((k_stream<true>), dim3(grid), dim3(RT_BLOCK), 0, st, S, V, sh, flags, tune.refill_min, tune.finish_min, tune.vote_node, tune.vote_tri, (float4 *)rgba, prim, t, counters);
+        else hipLaunchKernelGGL((k_stream<false>), dim3(grid), dim3(RT_BLOCK), 0, st, S, V, sh, flags, tune.refill_min, tune.finish_min, tune.vote_node, tune.vote_tri, (float4 *)rgba, prim, t, counters);
         return hipGetLastError();
     }
 #define RT_LAUNCH_PRIMARY(C, P) \

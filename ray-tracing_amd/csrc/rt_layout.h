@@ -67,10 +67,13 @@ struct RtShardDev {
 
 // device counters block (64-bit each); index constants
 enum { RT_CNT_SHADOW = 0, RT_CNT_BOUNCE = 1, RT_CNT_NODES = 2, RT_CNT_TRIS = 3, RT_CNT_MESH = 4,
-       RT_CNT_QUEUE_A = 5, RT_CNT_QUEUE_B = 6, RT_CNT_PRIMARY = 7, RT_CNT_WORK = 8, RT_CNT_WNODE = 9, RT_CNT_WTRI = 10, RT_CNT_WALIVE = 11, RT_CNT_N = 12 };
+       RT_CNT_QUEUE_A = 5, RT_CNT_QUEUE_B = 6, RT_CNT_PRIMARY = 7, RT_CNT_WORK = 8, RT_CNT_WNODE = 9, RT_CNT_WTRI = 10, RT_CNT_WALIVE = 11,
+       RT_CNT_HEADS = 16,            // 8 per-XCD work-queue heads, one 128-B line each (16 x u64 apart)
+       RT_CNT_N = 16 + 8 * 16 };
 
 // path-tracing wavefront queue, SoA: 11 dwords per path
 struct RtPathQueue {
     float *ox, *oy, *oz, *dx, *dy, *dz, *cr, *cg, *cb;
     uint32_t *rng, *pixel;
 };
+

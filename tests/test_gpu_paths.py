@@ -22,7 +22,7 @@ def _golden(name):
 
 
 @pytest.mark.parametrize("name", ["default_64x36_shadow", "spheres8_48x32"])
-@pytest.mark.parametrize("extra", [0, rt.FLAG_WAVE_TRAVERSAL, rt.FLAG_PERSISTENT, rt.FLAG_BRUTE_FORCE])
+@pytest.mark.parametrize("extra", [0, rt.FLAG_WAVE_TRAVERSAL, rt.FLAG_STATIC_GRID, rt.FLAG_BRUTE_FORCE])
 def test_golden_fixtures(name, extra):
     g, scene, W, H = _golden(name)
     with rt.Context(0) as ctx:
@@ -199,7 +199,7 @@ def test_edge_cases_empty_scene_not_ready_and_bad_arguments():
         ctx.upload_scene(empty)
         assert ctx.render() == rt.RT_NOT_READY                     # still no view
         ctx.set_view(np.eye(4, dtype=np.float32).ravel(), (0, 0, 0), 33, 17)     # ragged size (not a tile multiple)
-        for f in (0, rt.FLAG_SHADOW, rt.FLAG_BRUTE_FORCE, rt.FLAG_WAVE_TRAVERSAL, rt.FLAG_PERSISTENT, rt.FLAG_PATH_TRACE):
+        for f in (0, rt.FLAG_SHADOW, rt.FLAG_BRUTE_FORCE, rt.FLAG_WAVE_TRAVERSAL, rt.FLAG_STATIC_GRID, rt.FLAG_PATH_TRACE):
             assert ctx.render(flags=f, spp=1) == rt.RT_OK
             assert np.all(ctx.read_prim_ids() == rt.MISS_PRIM)
         assert np.allclose(ctx.read_radiance()[..., :3], [0.5, 0.71, 0.86])       # path tracing: every path sees the sky
@@ -267,7 +267,7 @@ def test_full_size_properties_on_the_bench_workload():
     agree, rmse = parity(rgba.reshape(-1, 4)[pix], prim.ravel()[pix], rgba_o, prim_o)
     assert agree >= 0.999 and rmse <= 1e-3, (agree, rmse)
     assert bitwise_equal(prim.ravel()[pix], prim_o) and bitwise_equal(t.ravel()[pix], t_o)
-    for extra in (rt.FLAG_WAVE_TRAVERSAL, rt.FLAG_PERSISTENT):
+    for extra in (rt.FLAG_WAVE_TRAVERSAL, rt.FLAG_STATIC_GRID):
         _, rgba2, prim2, t2 = gpu_render(app, scene, rt.FLAG_SHADOW | extra, ctx=ctx)
         assert bitwise_equal(prim2, prim) and bitwise_equal(t2, t) and bitwise_equal(rgba2, rgba)
     total = np.zeros_like(rgba)

@@ -13,7 +13,7 @@ pytestmark = pytest.mark.gpu
 
 @pytest.mark.parametrize("flags", [0, rt.FLAG_SHADOW, rt.FLAG_BRUTE_FORCE, rt.FLAG_BRUTE_FORCE | rt.FLAG_SHADOW,
                                    rt.FLAG_NO_MESH_CULL, rt.FLAG_COUNTERS | rt.FLAG_SHADOW,
-                                   rt.FLAG_PERSISTENT, rt.FLAG_PERSISTENT | rt.FLAG_SHADOW,
+                                   rt.FLAG_STATIC_GRID, rt.FLAG_STATIC_GRID | rt.FLAG_SHADOW,
                                    rt.FLAG_WAVE_TRAVERSAL, rt.FLAG_WAVE_TRAVERSAL | rt.FLAG_SHADOW,
                                    rt.FLAG_WAVE_TRAVERSAL | rt.FLAG_SHADOW | rt.FLAG_COUNTERS])
 def test_default_scene_640x360(flags):
@@ -43,7 +43,7 @@ def test_soup_bvh_matches_oracle_and_brute_force():
     agree, rmse = parity(rgba_g, prim_g, rgba_o, prim_o)
     assert agree >= 0.999 and rmse <= 1e-3, (agree, rmse)
     assert bitwise_equal(prim_g, prim_o) and bitwise_equal(t_g, t_o) and bitwise_equal(rgba_g, rgba_o)
-    for f in (rt.FLAG_BRUTE_FORCE, rt.FLAG_WAVE_TRAVERSAL, rt.FLAG_PERSISTENT):
+    for f in (rt.FLAG_BRUTE_FORCE, rt.FLAG_WAVE_TRAVERSAL, rt.FLAG_STATIC_GRID):
         _, rgba_b, prim_b, t_b = gpu_render(app, scene, rt.FLAG_SHADOW | f, ctx=ctx)
         assert bitwise_equal(prim_b, prim_o) and bitwise_equal(t_b, t_o) and bitwise_equal(rgba_b, rgba_o)
     ctx.close()

@@ -8,7 +8,7 @@ ctx = rt.Context(0)
 def run(name, app, W, H):
     sc = app.prepare_meshinfo(); ctx.upload_scene(sc)
     app.camera_set_target(W,H); m,p = app.camera_view(); ctx.set_view(m,p,W,H)
-    for mode, fl in (("static",0),("packet",rt.FLAG_WAVE_TRAVERSAL),("persist",rt.FLAG_PERSISTENT),("brute",rt.FLAG_BRUTE_FORCE)):
+    for mode, fl in (("static",0),("packet",rt.FLAG_WAVE_TRAVERSAL),("persist",rt.FLAG_STATIC_GRID),("brute",rt.FLAG_BRUTE_FORCE)):
         if mode=="brute" and len(sc.triangles)>5000: continue
         f = rt.FLAG_SHADOW|fl
         for _ in range(3): ctx.render(flags=f)

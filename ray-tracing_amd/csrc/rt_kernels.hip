@@ -596,7 +596,18 @@ __global__ __launch_bounds__(RT_BLOCK, RT_MIN_WAVES) void k_stream(
                         if (lane == 0u) r = (uint32_t)atomicAdd(heads + q * 16u, 1ull);
                         r = (uint32_t)__builtin_amdgcn_readfirstlane((int)r);
                     }
-                    if (r >= len) { ++qoff; continue; }       // this queue is empty: next one
+                    if (r >= len) {
+                        // this queue is empty: ONE look at all eight heads (lanes 0..7), then on to the first queue
+                        // that still has regions -- not seven more dependent atomics before a wave may leave
+                        const uint32_t ql = (home + lane) & 7u;
+                        const uint32_t len_l = (sh.n_owned > ql ? (sh.n_owned - ql + 7u) / 8u : 0u) * rpt;
+                        bool avail = false;
+                        if (lane < 8u && lane > qoff)
+                            avail = __hip_atomic_load(heads + ql * 16u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned long long)len_l;
+                        const unsigned long long ma = __ballot(avail);
+                        qoff = ma ? (uint32_t)__builtin_ctzll(ma) : 8u;
+                        continue;
+                    }
                     reg_q = q; reg_r = r; reg_next = 0u;
                 }
                 if (state == 0) {

@@ -31,6 +31,7 @@ HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s meas
 WORKLOADS = {
     # name: (kind, count, seed, width, height[, spp, max_segments])   spp > 0 => path tracing (wgsl:180-202 shape)
     "sphere_field_10k_1080p_primary_shadow": ("field", 10000, 0x5EED0002, 1920, 1080),     # configs[1], the default
+    "sphere_field_10k_analytic_1080p_primary_shadow": ("field_analytic", 10000, 0x5EED0002, 1920, 1080),   # configs[1] variant (ii): extension
     "soup_1m_1080p_primary_shadow": ("soup", 1389, 0x5EED0003, 1920, 1080),
     "soup_1m_1080p_4spp": ("soup", 1389, 0x5EED0003, 1920, 1080, 4, 1),                    # configs[2]: jittered primaries
     "soup_1m_4k_path_4spp_4seg": ("soup", 1389, 0x5EED0003, 3840, 2160, 4, 4),             # configs[3] per 4 of its 64 spp
@@ -48,6 +49,9 @@ def build_app(rt, workload, rank=0, world=1):
     # which flatters Mrays/s; at 1.0 radii 66 % (field) / 48 % (soup) of the pixels hit geometry.
     if kind == "field":
         app.spawn_sphere_field(count, seed, 5)
+        app.camera_frame_scene(CAMERA_RADII)
+    elif kind == "field_analytic":
+        app.spawn_sphere_field(count, seed, 0)   # same entities (icosahedra stand in): only the camera framing is taken from it
         app.camera_frame_scene(CAMERA_RADII)
     elif kind == "soup":
         app.spawn_icosphere_soup(count, seed, 5)
@@ -78,7 +82,8 @@ def orbit_camera(app, rank, world):
 def cpu_baseline(orc, scene, view, W, H, flags, target_seconds=15.0):
     """Time the oracle's reference-shaped brute-force loop on a bounded seeded pixel sample."""
     threads = max(1, min(16, os.cpu_count() or 1))
-    osc = orc.Scene(scene.triangles, scene.meshes, scene.vertices, scene.materials)
+    osc = orc.Scene(scene.triangles, scene.meshes, scene.vertices, scene.materials,
+                    getattr(scene, "spheres", None), getattr(scene, "sphere_materials", None))
     rng = np.random.default_rng(0x5EED)
     perm = rng.permutation(W * H).astype(np.uint32)
     oflags = orc.FLAG_SHADOW if flags & 1 else 0
@@ -137,6 +142,8 @@ def main():
     if world > 1 and not tiles:
         orbit_camera(app, rank, world)
     scene = app.prepare_meshinfo()            # P1: scene extraction (host)
+    if WORKLOADS[args.workload][0] == "field_analytic":
+        scene = rt.analytic_sphere_field(WORKLOADS[args.workload][1], WORKLOADS[args.workload][2])
     ctx = rt.Context(local_rank)
     stream = torch.cuda.current_stream()
     ctx.set_stream(stream.cuda_stream)        # kernels run on torch's stream: events below see them

@@ -45,6 +45,11 @@ typedef struct { float pos[3]; float _pad0; float norm[3]; float _pad1; } rt_ver
 /* T4  SimpleMaterial  src/ray_tracing.rs:65-68, ray_tracing.wgsl:32-34.  16 B. */
 typedef struct { float color[4]; } rt_material;
 
+/* EXTENSION (SURVEY 8d config 2 variant ii): analytic sphere, centre + radius as the dead Sphere type of
+ * src/scene.rs:26-28 has them.  The reference has no ray/sphere test (its live spheres are tessellated,
+ * src/main.rs:85): the test is build-defined (oracle/rt_oracle.h, orc_ray_sphere).  16 B. */
+typedef struct { float center[3]; float radius; } rt_sphere;
+
 typedef struct rt_ctx rt_ctx;
 
 /* ---- lifecycle: replaces RayTracingPipeline::from_world (src/pipeline.rs:25-72) ----- */
@@ -63,6 +68,17 @@ int rt_upload_scene(rt_ctx *ctx,
                     const rt_mesh_info *meshes, size_t n_meshes,
                     const rt_vertex *vertices, size_t n_vertices,
                     const rt_material *materials, size_t n_materials);
+
+/* EXTENSION: the same, plus analytic spheres.  Spheres come after every mesh in the reference's loop
+ * order (ties on t go to the triangle, then to the lower sphere index); a sphere's primitive id is
+ * n_triangles + its index; sphere_materials[i] indexes `materials`.  Only the entry point of a ray counts
+ * (an origin inside a sphere misses it, as back faces do for triangles, wgsl:137). */
+int rt_upload_scene_ex(rt_ctx *ctx,
+                       const rt_triangle *triangles, size_t n_triangles,
+                       const rt_mesh_info *meshes, size_t n_meshes,
+                       const rt_vertex *vertices, size_t n_vertices,
+                       const rt_material *materials, size_t n_materials,
+                       const rt_sphere *spheres, const uint32_t *sphere_materials, size_t n_spheres);
 
 /* Same scene, moved vertices (the reference rebuilds and re-uploads everything every
  * frame, src/ray_tracing.rs:113-168, and main.rs rotates the cube every frame, src/main.rs:122-126).
@@ -148,7 +164,7 @@ typedef struct {
 int rt_get_counters(rt_ctx *ctx, rt_counters *out);
 
 typedef struct {
-    uint64_t n_nodes, n_triangles, n_meshes, n_vertices;
+    uint64_t n_nodes, n_triangles, n_meshes, n_vertices;   /* n_triangles: leaf records (triangles + spheres) */
     uint32_t node_bytes, tri_bytes;  /* bytes per BVH node / per leaf triangle record */
     uint32_t max_depth, max_leaf;
     double   build_ms;               /* of the last build or refit */

@@ -22,6 +22,8 @@ pub struct rt_vertex { pub pos: [f32; 3], pub _pad0: f32, pub norm: [f32; 3], pu
 /// T4 SimpleMaterial, src/ray_tracing.rs:65-68 (16 B)
 #[repr(C)] #[derive(Clone, Copy, Default)]
 pub struct rt_material { pub color: [f32; 4] }
+#[repr(C)] #[derive(Clone, Copy, Default)]
+pub struct rt_sphere { pub center: [f32; 3], pub radius: f32 }
 
 #[repr(C)] #[derive(Clone, Copy, Default)]
 pub struct rt_render_params {
@@ -55,6 +57,11 @@ extern "C" {
     pub fn rt_upload_scene(ctx: *mut rt_ctx,
         triangles: *const rt_triangle, n_triangles: usize, meshes: *const rt_mesh_info, n_meshes: usize,
         vertices: *const rt_vertex, n_vertices: usize, materials: *const rt_material, n_materials: usize) -> c_int;
+    /// Extension: the same plus analytic spheres (centre + radius as `Sphere` in src/scene.rs:26-28).
+    pub fn rt_upload_scene_ex(ctx: *mut rt_ctx,
+        triangles: *const rt_triangle, n_triangles: usize, meshes: *const rt_mesh_info, n_meshes: usize,
+        vertices: *const rt_vertex, n_vertices: usize, materials: *const rt_material, n_materials: usize,
+        spheres: *const rt_sphere, sphere_materials: *const u32, n_spheres: usize) -> c_int;
     pub fn rt_update_vertices(ctx: *mut rt_ctx, vertices: *const rt_vertex, n_vertices: usize,
         meshes: *const rt_mesh_info, n_meshes: usize) -> c_int;
     pub fn rt_set_view(ctx: *mut rt_ctx, world_from_clip: *const f32, world_position: *const f32,

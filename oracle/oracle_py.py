@@ -21,11 +21,13 @@ MESH_INFO = np.dtype([("first_tri", "<u4"), ("tri_count", "<u4"), ("material", "
                       ("aabb_min", "<f4", 3), ("_pad1", "<f4"), ("aabb_max", "<f4", 3), ("_pad2", "<f4")])
 VERTEX = np.dtype([("pos", "<f4", 3), ("_pad0", "<f4"), ("norm", "<f4", 3), ("_pad1", "<f4")])
 MATERIAL = np.dtype([("color", "<f4", 4)])
+SPHERE = np.dtype([("center", "<f4", 3), ("radius", "<f4")])   # extension: analytic spheres (rt_oracle.h)
 
 
 class OScene(C.Structure):
     _fields_ = [("tris", C.c_void_p), ("n_tri", C.c_size_t), ("meshes", C.c_void_p), ("n_mesh", C.c_size_t),
-                ("verts", C.c_void_p), ("n_vtx", C.c_size_t), ("mats", C.c_void_p), ("n_mat", C.c_size_t)]
+                ("verts", C.c_void_p), ("n_vtx", C.c_size_t), ("mats", C.c_void_p), ("n_mat", C.c_size_t),
+                ("spheres", C.c_void_p), ("sphere_mats", C.c_void_p), ("n_sphere", C.c_size_t)]
 
 
 class OView(C.Structure):
@@ -66,6 +68,7 @@ def lib():
     L.orc_ray_aabb.restype = C.c_int
     L.orc_ray_triangle.argtypes = [C.POINTER(OScene), fp, fp, C.c_uint32, C.POINTER(OHit)]
     L.orc_hit_triangles.argtypes = [C.POINTER(OScene), fp, fp, C.c_uint32, C.POINTER(OHit)]
+    L.orc_ray_sphere.argtypes = [C.POINTER(OScene), fp, fp, C.c_uint32, C.POINTER(OHit)]
     L.orc_shade.argtypes = [C.POINTER(OScene), C.POINTER(OHit), fp]
     L.orc_render_primary.argtypes = [C.POINTER(OScene), C.POINTER(OView), C.c_uint32, C.c_void_p, C.c_void_p,
                                      C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
@@ -100,13 +103,18 @@ def _f3(a):
 
 
 class Scene:
-    def __init__(self, triangles, meshes, vertices, materials):
+    def __init__(self, triangles, meshes, vertices, materials, spheres=None, sphere_materials=None):
         self.triangles = np.ascontiguousarray(triangles, dtype=TRIANGLE)
         self.meshes = np.ascontiguousarray(meshes, dtype=MESH_INFO)
         self.vertices = np.ascontiguousarray(vertices, dtype=VERTEX)
         self.materials = np.ascontiguousarray(materials, dtype=MATERIAL)
+        self.spheres = np.ascontiguousarray(spheres if spheres is not None else np.zeros(0, SPHERE), dtype=SPHERE)
+        self.sphere_materials = np.ascontiguousarray(
+            sphere_materials if sphere_materials is not None else np.zeros(self.spheres.size, np.uint32), dtype=np.uint32)
+        assert self.sphere_materials.size == self.spheres.size
         self.c = OScene(self.triangles.ctypes.data, self.triangles.size, self.meshes.ctypes.data, self.meshes.size,
-                        self.vertices.ctypes.data, self.vertices.size, self.materials.ctypes.data, self.materials.size)
+                        self.vertices.ctypes.data, self.vertices.size, self.materials.ctypes.data, self.materials.size,
+                        self.spheres.ctypes.data, self.sphere_materials.ctypes.data, self.spheres.size)
 
 
 def make_view(world_from_clip, world_position, width, height, viewport=None):
@@ -141,6 +149,12 @@ def _hit(h):
 def ray_triangle(scene, o, d, tri):
     h = OHit()
     lib().orc_ray_triangle(C.byref(scene.c), _f3(o), _f3(d), tri, C.byref(h))
+    return _hit(h)
+
+
+def ray_sphere(scene, o, d, sphere):
+    h = OHit()
+    lib().orc_ray_sphere(C.byref(scene.c), _f3(o), _f3(d), sphere, C.byref(h))
     return _hit(h)
 
 

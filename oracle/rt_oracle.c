@@ -92,6 +92,25 @@ void orc_ray_triangle(const orc_scene *s, const float o[3], const float d[3], ui
     out->prim = tri;
 }
 
+/* ---- extension: ray / analytic sphere (build-defined; see rt_oracle.h) ----------------------- */
+void orc_ray_sphere(const orc_scene *s, const float o[3], const float d[3], uint32_t sphere, orc_hit *out) {
+    const orc_sphere *S = &s->spheres[sphere];
+    v3 ro = ld3(o), rd = ld3(d), c = ld3(S->center);
+    v3 oc = sub(ro, c);
+    float a = dot(rd, rd);
+    float hb = dot(oc, rd);
+    float cc = dot(oc, oc) - S->radius * S->radius;
+    float disc = hb * hb - a * cc;
+    float dst = (-hb - sqrtf(disc)) / a;
+    out->hit = disc >= 0.0f && dst >= 0.0f;
+    v3 p = add(ro, scl(rd, dst));
+    st3(out->point, p);
+    st3(out->normal, normalize(sub(p, c)));
+    out->t = dst;
+    out->material = s->sphere_mats ? s->sphere_mats[sphere] : 0u;
+    out->prim = (uint32_t)s->n_tri + sphere;
+}
+
 /* ---- A5 closest hit over meshes then triangles: wgsl:150-170 --------------------------- */
 void orc_hit_triangles(const orc_scene *s, const float o[3], const float d[3], uint32_t flags, orc_hit *out) {
     orc_hit hit;
@@ -108,6 +127,12 @@ void orc_hit_triangles(const orc_scene *s, const float o[3], const float d[3], u
             if (!rec.hit) continue;
             if (!hit.hit || hit.t > rec.t) hit = rec; /* strict: earlier wins ties (KAT-3) */
         }
+    }
+    for (size_t i = 0; i < s->n_sphere; ++i) { /* extension: spheres come after every mesh in loop order */
+        orc_hit rec;
+        orc_ray_sphere(s, o, d, (uint32_t)i, &rec);
+        if (!rec.hit) continue;
+        if (!hit.hit || hit.t > rec.t) hit = rec;
     }
     *out = hit;
 }

@@ -50,11 +50,19 @@ typedef struct { float pos[3]; float pad0; float norm[3]; float pad1; } orc_vert
 /* T4  src/ray_tracing.rs:65-68, wgsl:32-34 -- 16 B */
 typedef struct { float color[4]; } orc_material;
 
+/* Analytic sphere (EXTENSION, SURVEY 8d config 2 variant ii): centre + radius as the dead
+ * Sphere type of src/scene.rs:26-28 has them; the reference has no ray/sphere test (its live
+ * spheres are tessellated, src/main.rs:85), so this part of the oracle is BUILD-DEFINED and
+ * parity for it is unpinned by the reference.  16 B. */
+typedef struct { float center[3]; float radius; } orc_sphere;
+
 typedef struct {
     const orc_triangle *tris;    size_t n_tri;
     const orc_mesh_info *meshes; size_t n_mesh;
     const orc_vertex *verts;     size_t n_vtx;
     const orc_material *mats;    size_t n_mat;
+    /* extension: analytic spheres, tested after all meshes (prim id = n_tri + index) */
+    const orc_sphere *spheres;   const uint32_t *sphere_mats; size_t n_sphere;
 } orc_scene;
 
 /* Subset of Bevy's View uniform the shader reads (wgsl:176-177). Column-major mat4. */
@@ -85,6 +93,11 @@ void orc_ray_gen(const orc_view *v, uint32_t px, uint32_t py, float o[3], float 
 int  orc_ray_aabb(const float o[3], const float d[3], const float lb[3], const float rt[3]);
 void orc_ray_triangle(const orc_scene *s, const float o[3], const float d[3], uint32_t tri, orc_hit *out);
 void orc_hit_triangles(const orc_scene *s, const float o[3], const float d[3], uint32_t flags, orc_hit *out);
+/* Build-defined ray/sphere test (no reference counterpart): oc = o - c; a = dot(d,d); hb = dot(oc,d);
+ * cc = dot(oc,oc) - r*r; disc = hb*hb - a*cc; t = (-hb - sqrt(disc)) / a; hit iff disc >= 0 && t >= 0
+ * (entry point only: an origin inside the sphere misses, as back faces do for triangles, wgsl:137);
+ * normal = normalize(point - c). */
+void orc_ray_sphere(const orc_scene *s, const float o[3], const float d[3], uint32_t sphere, orc_hit *out);
 void orc_shade(const orc_scene *s, const orc_hit *h, float rgba[4]);
 
 /* --- whole frames ---------------------------------------------------------------- */

@@ -36,6 +36,7 @@ MESH_INFO = np.dtype([("first_tri", "<u4"), ("tri_count", "<u4"), ("material", "
                       ("aabb_min", "<f4", 3), ("_pad1", "<f4"), ("aabb_max", "<f4", 3), ("_pad2", "<f4")])
 VERTEX = np.dtype([("pos", "<f4", 3), ("_pad0", "<f4"), ("norm", "<f4", 3), ("_pad1", "<f4")])
 MATERIAL = np.dtype([("color", "<f4", 4)])
+SPHERE = np.dtype([("center", "<f4", 3), ("radius", "<f4")])   # extension: analytic spheres (rt_sphere)
 assert TRIANGLE.itemsize == 12 and MESH_INFO.itemsize == 48 and VERTEX.itemsize == 32 and MATERIAL.itemsize == 16
 
 BVH_NODE = np.dtype([("lo0", "<f4", 3), ("hi0", "<f4", 3), ("lo1", "<f4", 3), ("hi1", "<f4", 3),
@@ -72,7 +73,7 @@ class EntityView(C.Structure):
 
 
 # every symbol include/rt_amd.h and include/rt_host.h declare
-RT_SYMBOLS = ["rt_create", "rt_destroy", "rt_set_stream", "rt_upload_scene", "rt_update_vertices", "rt_host_bvh_refit", "rt_set_view", "rt_render",
+RT_SYMBOLS = ["rt_create", "rt_destroy", "rt_set_stream", "rt_upload_scene", "rt_upload_scene_ex", "rt_update_vertices", "rt_host_bvh_refit", "rt_set_view", "rt_render",
               "rt_synchronize", "rt_read_radiance", "rt_read_prim_ids", "rt_read_hit_t", "rt_read_bgra8_srgb",
               "rt_read_accumulation", "rt_device_buffers", "rt_resolve_accumulation", "rt_get_counters",
               "rt_get_bvh_info", "rt_read_bvh", "rt_host_bvh_build", "rt_host_bvh_copy", "rt_host_bvh_free", "rt_last_error", "rt_status_string", "rt_version"]
@@ -100,6 +101,7 @@ def lib():
     sig = {
         "rt_create": (i, [i, C.POINTER(vp)]), "rt_destroy": (i, [vp]), "rt_set_stream": (i, [vp, vp]),
         "rt_upload_scene": (i, [vp, vp, sz, vp, sz, vp, sz, vp, sz]),
+        "rt_upload_scene_ex": (i, [vp, vp, sz, vp, sz, vp, sz, vp, sz, vp, vp, sz]),
         "rt_update_vertices": (i, [vp, vp, sz, vp, sz]),
         "rt_host_bvh_refit": (i, [vp, vp, sz, vp, sz, i]),
         "rt_set_view": (i, [vp, fp, fp, u32, u32, C.POINTER(u32)]),
@@ -159,11 +161,48 @@ def _fp(a):
 class Scene:
     """Host arrays in the T1-T4 layouts (what RayTracingInfo holds)."""
 
-    def __init__(self, triangles, meshes, vertices, materials):
+    def __init__(self, triangles, meshes, vertices, materials, spheres=None, sphere_materials=None):
         self.triangles = np.ascontiguousarray(triangles, dtype=TRIANGLE)
         self.meshes = np.ascontiguousarray(meshes, dtype=MESH_INFO)
         self.vertices = np.ascontiguousarray(vertices, dtype=VERTEX)
         self.materials = np.ascontiguousarray(materials, dtype=MATERIAL)
+        # extension: analytic spheres (rt_upload_scene_ex); sphere_materials[i] indexes `materials`
+        self.spheres = np.ascontiguousarray(spheres if spheres is not None else np.zeros(0, SPHERE), dtype=SPHERE)
+        self.sphere_materials = np.ascontiguousarray(
+            sphere_materials if sphere_materials is not None else np.zeros(self.spheres.size, np.uint32), dtype=np.uint32)
+        if self.sphere_materials.size != self.spheres.size:
+            raise ValueError("one material index per sphere")
+
+
+def analytic_sphere_field(n, seed):
+    """SURVEY 8d config 2, variant (ii): the sphere field of App.spawn_sphere_field as ANALYTIC spheres
+    (same SplitMix64 stream, so the same centres, radii and colours as the tessellated field) over the same
+    ground plane mesh."""
+    app = App()
+    app.spawn_sphere_field(0, seed, 0)          # the ground plane and its material only
+    ground = app.prepare_meshinfo()
+    app.close()
+    f32 = np.float32
+    state = [int(seed) & 0xFFFFFFFFFFFFFFFF]
+
+    def uniform(lo, hi):                        # SplitMix64 + 24-bit mantissa, as host/ray_tracing.cpp
+        state[0] = (state[0] + 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF
+        z = state[0]
+        z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & 0xFFFFFFFFFFFFFFFF
+        z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & 0xFFFFFFFFFFFFFFFF
+        z ^= z >> 31
+        u = f32(z >> 40) * f32(1.0 / 16777216.0)
+        return f32(lo) + (f32(hi) - f32(lo)) * u
+
+    spheres = np.zeros(n, SPHERE)
+    mats = np.zeros(ground.materials.size + n, MATERIAL)
+    mats[:ground.materials.size] = ground.materials
+    for k in range(n):
+        spheres["center"][k] = (uniform(-50.0, 50.0), uniform(0.0, 20.0), uniform(-50.0, 50.0))
+        spheres["radius"][k] = uniform(0.2, 0.8)
+        mats["color"][ground.materials.size + k] = (uniform(0.1, 1.0), uniform(0.1, 1.0), uniform(0.1, 1.0), 1.0)
+    idx = np.arange(ground.materials.size, ground.materials.size + n, dtype=np.uint32)
+    return Scene(ground.triangles, ground.meshes, ground.vertices, mats, spheres, idx)
 
 
 def host_bvh_build(scene, threads=0, refit_to=None):
@@ -224,6 +263,11 @@ class Context:
 
     def upload_scene(self, scene):
         t, m, v, c = scene.triangles, scene.meshes, scene.vertices, scene.materials
+        sp, sm = getattr(scene, "spheres", None), getattr(scene, "sphere_materials", None)
+        if sp is not None and sp.size:
+            return self._chk(lib().rt_upload_scene_ex(self._h, t.ctypes.data, t.size, m.ctypes.data, m.size,
+                                                      v.ctypes.data, v.size, c.ctypes.data, c.size,
+                                                      sp.ctypes.data, sm.ctypes.data, sp.size))
         return self._chk(lib().rt_upload_scene(self._h, t.ctypes.data, t.size, m.ctypes.data, m.size,
                                                v.ctypes.data, v.size, c.ctypes.data, c.size))
 

@@ -163,8 +163,9 @@ inline int32_t leaf_code(uint32_t first, uint32_t count) { return ~(int32_t)((fi
 }  // namespace
 
 void rt_bvh_build(const rt_triangle *tris, size_t n_tris, const rt_mesh_info *meshes, size_t n_meshes,
-                  const rt_vertex *verts, size_t n_verts, int n_threads, RtBvhBuildResult *out) {
-    (void)n_tris; (void)n_verts;
+                  const rt_vertex *verts, size_t n_verts, int n_threads, RtBvhBuildResult *out,
+                  const rt_sphere *spheres, size_t n_spheres) {
+    (void)n_verts;
     auto t0 = std::chrono::steady_clock::now();
     out->nodes.clear(); out->recs.clear();
     out->max_depth = 0; out->max_leaf = 0; out->sah_cost = 0.0; out->dropped = 0;
@@ -174,7 +175,7 @@ void rt_bvh_build(const rt_triangle *tris, size_t n_tris, const rt_mesh_info *me
     Builder B;
     size_t total = 0;
     for (size_t m = 0; m < n_meshes; ++m) total += meshes[m].tri_count;
-    B.prims.reserve(total);
+    B.prims.reserve(total + n_spheres);
     uint32_t seq = 0;
     for (size_t m = 0; m < n_meshes; ++m) {
         for (uint32_t j = meshes[m].first_tri; j < meshes[m].first_tri + meshes[m].tri_count; ++j, ++seq) {
@@ -204,6 +205,27 @@ void rt_bvh_build(const rt_triangle *tris, size_t n_tris, const rt_mesh_info *me
             B.prims.push_back(P);
         }
     }
+    for (size_t i = 0; i < n_spheres; ++i, ++seq) {
+        const rt_sphere &sp = spheres[i];
+        Prim P;
+        bool finite = std::isfinite(sp.radius);
+        float amax = 0.0f;
+        float r = std::fabs(sp.radius);
+        for (int k = 0; k < 3; ++k) {
+            finite = finite && std::isfinite(sp.center[k]);
+            P.lo[k] = sp.center[k] - r; P.hi[k] = sp.center[k] + r;
+            amax = std::max(amax, std::max(std::fabs(P.lo[k]), std::fabs(P.hi[k])));
+        }
+        if (!finite) { out->dropped++; continue; }
+        // same padding rule as triangles, plus the rounding of centre +/- radius itself
+        float pad = 2e-5f * amax + 1e-30f;
+        for (int k = 0; k < 3; ++k) {
+            P.lo[k] -= pad; P.hi[k] += pad;
+            P.c[k] = 0.5f * P.lo[k] + 0.5f * P.hi[k];
+        }
+        P.seq = seq; P.tri = (uint32_t)(n_tris + i); P.mesh = RT_REC_SPHERE;
+        B.prims.push_back(P);
+    }
     size_t n = B.prims.size();
     if (n == 0) { out->build_ms = 0.0; return; }
 
@@ -221,6 +243,15 @@ void rt_bvh_build(const rt_triangle *tris, size_t n_tris, const rt_mesh_info *me
     out->recs.resize(n);
     for (size_t i = 0; i < n; ++i) {
         const Prim &P = B.prims[i];
+        if (P.mesh == RT_REC_SPHERE) {
+            const rt_sphere &sp = spheres[P.tri - n_tris];
+            RtTriRecord &R = out->recs[i];
+            std::memset(&R, 0, sizeof R);
+            R.a[0] = sp.center[0]; R.a[1] = sp.center[1]; R.a[2] = sp.center[2];
+            R.abx = sp.radius;
+            R.tri = P.tri; R.mesh = RT_REC_SPHERE; R.seq = P.seq;
+            continue;
+        }
         const float *a = verts[tris[P.tri].indices[0]].pos;
         const float *b = verts[tris[P.tri].indices[1]].pos;
         const float *c = verts[tris[P.tri].indices[2]].pos;
@@ -289,7 +320,9 @@ void rt_bvh_build(const rt_triangle *tris, size_t n_tris, const rt_mesh_info *me
     out->build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
 }
 
-bool rt_bvh_refit(RtBvhBuildResult *bvh, const rt_triangle *tris, const rt_vertex *verts, int n_threads) {
+bool rt_bvh_refit(RtBvhBuildResult *bvh, const rt_triangle *tris, const rt_vertex *verts, int n_threads,
+                  const rt_sphere *spheres, size_t n_tris) {
+    (void)spheres; (void)n_tris;
     auto t0 = std::chrono::steady_clock::now();
     const size_t n = bvh->recs.size();
     if (n == 0) return true;
@@ -304,6 +337,13 @@ bool rt_bvh_refit(RtBvhBuildResult *bvh, const rt_triangle *tris, const rt_verte
     auto bake = [&](size_t b, size_t e) {
         for (size_t i = b; i < e; ++i) {
             RtTriRecord &R = bvh->recs[i];
+            if (R.mesh == RT_REC_SPHERE) {     // spheres do not move in a vertex update: same box as at build time
+                float r = std::fabs(R.abx), amax = 0.0f;
+                for (int k = 0; k < 3; ++k) amax = std::max(amax, std::max(std::fabs(R.a[k] - r), std::fabs(R.a[k] + r)));
+                float pad = 2e-5f * amax + 1e-30f;
+                for (int k = 0; k < 3; ++k) { blo[3 * i + k] = R.a[k] - r - pad; bhi[3 * i + k] = R.a[k] + r + pad; }
+                continue;
+            }
             const float *a = verts[tris[R.tri].indices[0]].pos;
             const float *bb = verts[tris[R.tri].indices[1]].pos;
             const float *c = verts[tris[R.tri].indices[2]].pos;

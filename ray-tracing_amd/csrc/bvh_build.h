@@ -16,11 +16,14 @@ struct RtBvhBuildResult {
 // Flattens the (mesh, triangle) loop of ray_tracing.wgsl:153,158 into records and builds the
 // tree.  Inputs must already be validated (indices in range).  n_threads <= 0: hardware
 // concurrency capped at 16.
+// Spheres (extension) become records after the triangles' (seq continues), boxed centre +/- radius.
 void rt_bvh_build(const rt_triangle *tris, size_t n_tris, const rt_mesh_info *meshes, size_t n_meshes,
-                  const rt_vertex *verts, size_t n_verts, int n_threads, RtBvhBuildResult *out);
+                  const rt_vertex *verts, size_t n_verts, int n_threads, RtBvhBuildResult *out,
+                  const rt_sphere *spheres = nullptr, size_t n_spheres = 0);
 
 // f1: vertices moved, topology unchanged.  Re-bakes every leaf record from the new vertex
 // positions and refits all boxes bottom-up in place (children are stored after their parent, so one
 // reverse sweep suffices).  Returns false when a vertex became non-finite (the tree would have to drop
 // that triangle): the caller then rebuilds.
-bool rt_bvh_refit(RtBvhBuildResult *bvh, const rt_triangle *tris, const rt_vertex *verts, int n_threads);
+bool rt_bvh_refit(RtBvhBuildResult *bvh, const rt_triangle *tris, const rt_vertex *verts, int n_threads,
+                  const rt_sphere *spheres = nullptr, size_t n_tris = 0);

@@ -34,7 +34,7 @@ struct rt_ctx {
     bool has_scene = false;
     RtSceneDev S{};
     void *d_nodes = nullptr, *d_recs = nullptr, *d_tris = nullptr, *d_meshes = nullptr, *d_verts = nullptr,
-         *d_mats = nullptr;
+         *d_mats = nullptr, *d_spheres = nullptr, *d_sphere_mats = nullptr;
     rt_bvh_info info{};
     RtBvhBuildResult bvh_host;            // retained for refits (rt_update_vertices)
     std::vector<rt_triangle> h_tris;      // topology of the uploaded scene
@@ -89,6 +89,7 @@ void free_dev(void *&p) { if (p) { (void)hipFree(p); p = nullptr; } }
 void free_scene(rt_ctx *c) {
     free_dev(c->d_nodes); free_dev(c->d_recs); free_dev(c->d_tris);
     free_dev(c->d_meshes); free_dev(c->d_verts); free_dev(c->d_mats);
+    free_dev(c->d_spheres); free_dev(c->d_sphere_mats);
     c->has_scene = false;
     std::memset(&c->S, 0, sizeof c->S);
 }
@@ -308,8 +309,22 @@ void rt_host_bvh_free(rt_host_bvh *h) { delete h; }
 
 int rt_upload_scene(rt_ctx *c, const rt_triangle *tris, size_t n_tris, const rt_mesh_info *meshes, size_t n_meshes,
                     const rt_vertex *verts, size_t n_verts, const rt_material *mats, size_t n_mats) {
+    return rt_upload_scene_ex(c, tris, n_tris, meshes, n_meshes, verts, n_verts, mats, n_mats, nullptr, nullptr, 0);
+}
+
+int rt_upload_scene_ex(rt_ctx *c, const rt_triangle *tris, size_t n_tris, const rt_mesh_info *meshes, size_t n_meshes,
+                       const rt_vertex *verts, size_t n_verts, const rt_material *mats, size_t n_mats,
+                       const rt_sphere *spheres, const uint32_t *sphere_mats, size_t n_spheres) {
     if (!c) return RT_ERR_ARG;
     if (n_mats && !mats) return fail(c, RT_ERR_ARG, "rt_upload_scene: NULL materials with non-zero count");
+    if (n_spheres && (!spheres || !sphere_mats)) return fail(c, RT_ERR_ARG, "rt_upload_scene_ex: NULL sphere arrays with non-zero count");
+    if (n_spheres >= (1u << 28) || n_tris + n_spheres >= 0xFFFFFFFFull)
+        return fail(c, RT_ERR_ARG, "rt_upload_scene_ex: too many spheres");
+    {
+        uint64_t items = n_spheres;
+        for (size_t m = 0; m < n_meshes && meshes; ++m) items += meshes[m].tri_count;
+        if (items >= (1u << 28)) return fail(c, RT_ERR_ARG, "rt_upload_scene_ex: too many leaf records (2^28 max)");
+    }
     // validate before touching the GPU: a kernel must never see an out-of-range index
     {
         int vrc = validate_scene(c, tris, n_tris, meshes, n_meshes, verts, n_verts);
@@ -322,7 +337,7 @@ int rt_upload_scene(rt_ctx *c, const rt_triangle *tris, size_t n_tris, const rt_
 
     RtBvhBuildResult bvh;
     try {
-        rt_bvh_build(tris, n_tris, meshes, n_meshes, verts, n_verts, 0, &bvh);
+        rt_bvh_build(tris, n_tris, meshes, n_meshes, verts, n_verts, 0, &bvh, spheres, n_spheres);
     } catch (const std::bad_alloc &) {
         return fail(c, RT_ERR_OOM, "rt_upload_scene: host allocation failed in the BVH build");
     }
@@ -335,6 +350,8 @@ int rt_upload_scene(rt_ctx *c, const rt_triangle *tris, size_t n_tris, const rt_
     if ((rc = upload(c, c->d_meshes, meshes, n_meshes)) != RT_OK) return rc;
     if ((rc = upload(c, c->d_verts, verts, n_verts)) != RT_OK) return rc;
     if ((rc = upload(c, c->d_mats, mats, n_mats)) != RT_OK) return rc;
+    if ((rc = upload(c, c->d_spheres, spheres, n_spheres)) != RT_OK) return rc;
+    if ((rc = upload(c, c->d_sphere_mats, sphere_mats, n_spheres)) != RT_OK) return rc;
     HIPCHK(c, hipStreamSynchronize(c->stream));   // host arrays are borrowed for this call only
 
     c->S.nodes = (const RtBvhNode *)c->d_nodes;
@@ -343,6 +360,9 @@ int rt_upload_scene(rt_ctx *c, const rt_triangle *tris, size_t n_tris, const rt_
     c->S.meshes = (const rt_mesh_info *)c->d_meshes;
     c->S.verts = (const rt_vertex *)c->d_verts;
     c->S.mats = (const rt_material *)c->d_mats;
+    c->S.spheres = (const rt_sphere *)c->d_spheres;
+    c->S.sphere_mats = (const uint32_t *)c->d_sphere_mats;
+    c->S.n_spheres = (uint32_t)n_spheres;
     c->S.n_nodes = (uint32_t)bvh.nodes.size();
     c->S.n_recs = (uint32_t)bvh.recs.size();
     c->S.n_tris = (uint32_t)n_tris;

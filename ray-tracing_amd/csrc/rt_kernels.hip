@@ -74,6 +74,27 @@ __device__ __forceinline__ bool ray_tri(f3 o, f3 d, f3 a, f3 ab, f3 ac, float &d
     return det >= 1e-6f && dst >= 0.0f && u >= 0.0f && v >= 0.0f && w >= 0.0f;
 }
 
+struct q4 { float x, y, z, w; };
+// ---- extension: ray / analytic sphere (build-defined; oracle orc_ray_sphere, same operation order) ----------
+__device__ __forceinline__ bool ray_sphere(f3 o, f3 d, f3 c, float r, float &dst) {
+    f3 oc = sub(o, c);
+    float a = dot(d, d);
+    float hb = dot(oc, d);
+    float cc = dot(oc, oc) - r * r;
+    float disc = hb * hb - a * cc;
+    dst = (-hb - sqrtf(disc)) / a;
+    return disc >= 0.0f && dst >= 0.0f;      // entry point only: an origin inside the sphere misses it
+}
+// one 48-B leaf record against the ray: a triangle (a, ab, ac) or a sphere (centre, radius; mesh = RT_REC_SPHERE)
+template <class Q>   // Q: float4, or the broadcast q4 of the wave-coherent traversal
+__device__ __forceinline__ bool prim_test(f3 o, f3 d, Q r0, Q r1, Q r2, float &dst, float &u, float &v) {
+    if (__float_as_uint(r2.z) == RT_REC_SPHERE) {
+        u = 0.0f; v = 0.0f;
+        return ray_sphere(o, d, F3(r0.x, r0.y, r0.z), r0.w, dst);
+    }
+    return ray_tri(o, d, F3(r0.x, r0.y, r0.z), F3(r0.w, r1.x, r1.y), F3(r1.z, r1.w, r2.x), dst, u, v);
+}
+
 struct Hit {
     float t, u, v;
     uint32_t seq, tri, mesh;
@@ -172,11 +193,11 @@ __device__ __forceinline__ void traverse(const RtSceneDev &S, f3 o, f3 d, uint32
                     float4 r0 = r[0], r1 = r[1], r2 = r[2];
                     if (COUNT) { c.tris++; if ((threadIdx.x & 63u) == (uint32_t)__builtin_ctzll(__ballot(true))) c.wtris++; }
                     float dst, u, v;
-                    bool ok = ray_tri(o, d, F3(r0.x, r0.y, r0.z), F3(r0.w, r1.x, r1.y), F3(r1.z, r1.w, r2.x), dst, u, v);
+                    bool ok = prim_test(o, d, r0, r1, r2, dst, u, v);
                     uint32_t seq = __float_as_uint(r2.w);
                     ok = ok && (dst < h.t || (dst == h.t && seq < h.seq));
                     uint32_t mesh = __float_as_uint(r2.z);
-                    if (ok && !(flags & RT_FLAG_NO_MESH_CULL)) {   // per-mesh AABB cull of wgsl:155
+                    if (ok && !(flags & RT_FLAG_NO_MESH_CULL) && mesh != RT_REC_SPHERE) {   // per-mesh AABB cull of wgsl:155
                         const float4 *mp = reinterpret_cast<const float4 *>(S.meshes + mesh);
                         float4 m1 = mp[1], m2 = mp[2];
                         ok = ray_aabb_ref(o, inv, F3(m1.x, m1.y, m1.z), F3(m2.x, m2.y, m2.z));
@@ -209,7 +230,6 @@ __device__ __forceinline__ void traverse(const RtSceneDev &S, f3 o, f3 d, uint32
 // vector-memory request per wave -- and the dwords are then broadcast to SGPRs with v_readlane.
 // (Scalar-cache s_load was tried first: its miss path serialises and ran 1.4x slower than the
 // per-lane kernel on a 7.2 M-triangle scene; the vector L1 keeps many misses in flight.)
-struct q4 { float x, y, z, w; };
 __device__ __forceinline__ float wave_fetch16(const void *rec) {
     return reinterpret_cast<const float *>(rec)[threadIdx.x & 15u];
 }
@@ -274,12 +294,12 @@ __device__ __forceinline__ void traverse_packet(const RtSceneDev &S, f3 o, f3 d,
                 q4 r0 = RT_BCAST4(rv, 0), r1 = RT_BCAST4(rv, 1), r2 = RT_BCAST4(rv, 2);
                 if (COUNT) c.tris += lane0 ? 1u : 0u;
                 float dst, u, v;
-                bool ok = ray_tri(o, d, F3(r0.x, r0.y, r0.z), F3(r0.w, r1.x, r1.y), F3(r1.z, r1.w, r2.x), dst, u, v);
+                bool ok = prim_test(o, d, r0, r1, r2, dst, u, v);
                 uint32_t seq = __float_as_uint(r2.w);
                 ok = ok && alive && (dst < h.t || (dst == h.t && seq < h.seq));
                 if (__ballot(ok) == 0ull) continue;
                 uint32_t mesh = __float_as_uint(r2.z);
-                if (!(flags & RT_FLAG_NO_MESH_CULL)) {
+                if (!(flags & RT_FLAG_NO_MESH_CULL) && mesh != RT_REC_SPHERE) {
                     if (mesh != last_mesh) {      // wave-uniform: the whole wave looks at one triangle
                         float mv = wave_fetch16(S.meshes + mesh);   // 48-B MeshInfo, same 64-B window rule
                         q4 m1v = RT_BCAST4(mv, 1), m2v = RT_BCAST4(mv, 2);
@@ -334,6 +354,16 @@ __device__ __forceinline__ void brute_force(const RtSceneDev &S, f3 o, f3 d, uin
             }
         }
     }
+    for (uint32_t i = 0; i < S.n_spheres; ++i) {   // extension: spheres come after every mesh in loop order
+        float4 sp = *reinterpret_cast<const float4 *>(S.spheres + i);
+        if (COUNT) c.tris++;
+        float dst;
+        if (!ray_sphere(o, d, F3(sp.x, sp.y, sp.z), sp.w, dst)) continue;
+        if (!h.hit || h.t > dst) {
+            h.hit = true; h.t = dst; h.u = 0.0f; h.v = 0.0f; h.tri = S.n_tris + i; h.mesh = RT_REC_SPHERE;
+            if (ANY) return;
+        }
+    }
 }
 
 template <bool ANY, bool COUNT>
@@ -345,6 +375,14 @@ __device__ __forceinline__ void trace(const RtSceneDev &S, f3 o, f3 d, uint32_t 
 // point and interpolated vertex normal of an accepted hit: ray_tracing.wgsl:137-138
 __device__ __forceinline__ void finish_hit(const RtSceneDev &S, f3 o, f3 d, const Hit &h, f3 &point, f3 &normal,
                                            uint32_t &material) {
+    if (h.mesh == RT_REC_SPHERE) {      // extension: normal = normalize(point - centre)
+        uint32_t i = h.tri - S.n_tris;
+        float4 sp = *reinterpret_cast<const float4 *>(S.spheres + i);
+        point = add(o, scl(d, h.t));
+        normal = normalize(sub(point, F3(sp.x, sp.y, sp.z)));
+        material = S.sphere_mats[i];
+        return;
+    }
     rt_triangle T = S.tris[h.tri];
     const float4 *pa = reinterpret_cast<const float4 *>(S.verts + T.indices[0]);
     const float4 *pb = reinterpret_cast<const float4 *>(S.verts + T.indices[1]);
@@ -676,10 +714,10 @@ __global__ __launch_bounds__(RT_BLOCK, RT_MIN_WAVES) void k_stream(
                         float4 r0 = r[0], r1 = r[1], r2 = r[2];
                         if (COUNT) { c.tris++; if (lane == (uint32_t)__builtin_ctzll(__ballot(true))) c.wtris++; }
                         float dst, u, v;
-                        bool ok = ray_tri(o, d, F3(r0.x, r0.y, r0.z), F3(r0.w, r1.x, r1.y), F3(r1.z, r1.w, r2.x), dst, u, v);
+                        bool ok = prim_test(o, d, r0, r1, r2, dst, u, v);
                         uint32_t sq = __float_as_uint(r2.w);
                         ok = ok && (dst < t || (dst == t && sq < seq));
-                        if (ok && !(flags & RT_FLAG_NO_MESH_CULL)) {   // per-mesh AABB cull of wgsl:155
+                        if (ok && !(flags & RT_FLAG_NO_MESH_CULL) && __float_as_uint(r2.z) != RT_REC_SPHERE) {   // per-mesh AABB cull of wgsl:155
                             const float4 *mp = reinterpret_cast<const float4 *>(meshes + __float_as_uint(r2.z));
                             float4 m1 = mp[1], m2 = mp[2];
                             ok = ray_aabb_ref(o, inv, F3(m1.x, m1.y, m1.z), F3(m2.x, m2.y, m2.z));

@@ -36,6 +36,10 @@ struct alignas(16) RtTriRecord {
     float acz; uint32_t tri, mesh, seq;
 };
 static_assert(sizeof(RtTriRecord) == 48, "tri record must be 48 B");
+// An analytic sphere (extension) uses the same 48-B slot: a = centre, abx = radius, the other edge
+// floats 0, tri = n_triangles + sphere index (its primitive id), mesh = RT_REC_SPHERE, seq after
+// every triangle's.
+#define RT_REC_SPHERE 0xFFFFFFFFu
 
 static_assert(sizeof(rt_triangle) == 12, "T1");
 static_assert(sizeof(rt_mesh_info) == 48, "T2");
@@ -49,7 +53,9 @@ struct RtSceneDev {
     const rt_mesh_info *meshes;
     const rt_vertex *verts;
     const rt_material *mats;
-    uint32_t n_nodes, n_recs, n_tris, n_meshes, n_verts, n_mats;
+    const rt_sphere *spheres;          // extension: analytic spheres and their material indices
+    const uint32_t *sphere_mats;
+    uint32_t n_nodes, n_recs, n_tris, n_meshes, n_verts, n_mats, n_spheres, pad_;
 };
 
 struct RtViewDev {

@@ -523,14 +523,14 @@ int rt_render(rt_ctx *c, const rt_render_params *params) {
         for (uint32_t s = 0; s < P.spp; ++s) {
             HIPCHK(c, hipMemsetAsync(c->d_cnt + RT_CNT_QUEUE_A, 0, 2 * sizeof(unsigned long long), c->stream));
             HIPCHK(c, rtk_launch_path_start(c->stream, c->S, c->V, sh, P.flags, P.sample_first + s, P.seed, P.stream_id,
-                                            P.max_segments, c->d_accum, qa, c->d_cnt, RT_CNT_QUEUE_A));
+                                            P.max_segments, c->d_accum, qa, c->d_cnt, RT_CNT_QUEUE_A, c->tune));
             ++launches;
             int in = RT_CNT_QUEUE_A, out = RT_CNT_QUEUE_B;
             for (uint32_t seg = 1; seg < P.max_segments; ++seg) {
                 HIPCHK(c, hipMemsetAsync(c->d_cnt + out, 0, sizeof(unsigned long long), c->stream));
                 HIPCHK(c, rtk_launch_path_bounce(c->stream, c->S, P.flags, cap, seg + 1 == P.max_segments, c->d_accum,
                                                  in == RT_CNT_QUEUE_A ? qa : qb, in == RT_CNT_QUEUE_A ? qb : qa,
-                                                 c->d_cnt, in, out));
+                                                 c->d_cnt, in, out, c->tune));
                 ++launches;
                 int tmp = in; in = out; out = tmp;
             }

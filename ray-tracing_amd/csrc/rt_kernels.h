@@ -29,10 +29,10 @@ hipError_t rtk_launch_primary(hipStream_t st, const RtSceneDev &S, const RtViewD
 hipError_t rtk_launch_path_start(hipStream_t st, const RtSceneDev &S, const RtViewDev &V, const RtShardDev &sh,
                                  uint32_t flags, uint32_t sample, uint32_t seed, uint32_t stream_id,
                                  uint32_t max_segments, float *accum, RtPathQueue qout,
-                                 unsigned long long *counters, int qout_counter);
+                                 unsigned long long *counters, int qout_counter, const RtTune &tune);
 hipError_t rtk_launch_path_bounce(hipStream_t st, const RtSceneDev &S, uint32_t flags, uint32_t capacity,
                                   int is_last, float *accum, RtPathQueue qin, RtPathQueue qout,
-                                  unsigned long long *counters, int qin_counter, int qout_counter);
+                                  unsigned long long *counters, int qin_counter, int qout_counter, const RtTune &tune);
 
 hipError_t rtk_launch_resolve(hipStream_t st, const float *accum, float *rgba, size_t n_px, float inv_unused,
                               uint32_t total_samples);

@@ -403,11 +403,10 @@ __device__ __forceinline__ void finish_hit(const RtSceneDev &S, f3 o, f3 d, cons
 // contiguous screen band was measured first: the sky XCDs idled, 2.5 waves/SIMD on average.)
 // Speed only, never correctness: the mapping is a bijection whatever the placement.
 __device__ __forceinline__ bool pixel_of_thread(const RtViewDev &V, const RtShardDev &sh, uint32_t nb,
-                                                uint32_t &px, uint32_t &py) {
+                                                uint32_t &px, uint32_t &py, uint32_t b = blockIdx.x) {
     (void)nb;
     uint32_t sub = sh.tile / RT_WORK_TILE;
     uint32_t per_tile = sub * sub;
-    uint32_t b = blockIdx.x;
     uint32_t xcd = b & 7u, j = b >> 3;
     uint32_t k = (j / per_tile) * 8u + xcd;      // owned-tile ordinal of this block
     uint32_t s = j % per_tile;                   // 16x16 sub-block inside the tile
@@ -852,39 +851,49 @@ __device__ __forceinline__ bool path_segment(const RtSceneDev &S, uint32_t flags
     return false;
 }
 
+// persist != 0: one chip-full of blocks strides over the frame's 16x16 pixel blocks; persist == 0
+// (RT_FLAG_STATIC_GRID): one block per pixel block.  (Fed from k_stream's per-XCD queues instead, this kernel
+// ran 10 % slower at 1080p than the static grid.)
 template <bool COUNT>
 __global__ __launch_bounds__(RT_BLOCK, RT_MIN_WAVES) void k_path_start(RtSceneDev S, RtViewDev V, RtShardDev sh, uint32_t nb,
                                                          uint32_t flags, uint32_t sample, uint32_t seed,
                                                          uint32_t stream_id, uint32_t max_segments,
                                                          float4 *__restrict__ accum, RtPathQueue qo,
-                                                         unsigned long long *__restrict__ counters, int qo_ctr) {
+                                                         unsigned long long *__restrict__ counters, int qo_ctr,
+                                                         uint32_t persist) {
     __shared__ int s_stack[RT_STACK_LDS * RT_BLOCK];
     int *stk = s_stack + threadIdx.x;
-    uint32_t px, py;
-    bool active = pixel_of_thread(V, sh, nb, px, py);
     Cnt c; c.nodes = 0; c.tris = 0; c.meshes = 0; c.wnodes = 0; c.wtris = 0; c.walive = 0;
-    bool alive = false;
-    f3 o, d, col; uint32_t rng = 0, pixel = 0;
-    if (active) {
-        pixel = py * V.width + px;
-        f3 d0;
-        ray_gen(V, px, py, o, d0);
-        rng = rt_seed(pixel, sample, seed, stream_id);
-        float jx = rt_rand(rng), jy = rt_rand(rng);
-        d = add(d0, scl(F3(jx, jy, 0.0f), 0.0015f));   // wgsl:184, not renormalised
-        col = F3(1.0f, 1.0f, 1.0f);
-        float4 *acc = accum + pixel;
-        float4 a = *acc; a.w = a.w + 1.0f; *acc = a;   // one more sample for this pixel
-        alive = path_segment<COUNT>(S, flags, stk, o, d, col, rng, acc, c) && max_segments > 1;
+    uint32_t n_primary = 0;
+    // grid-stride over the nb 16x16 pixel blocks of the frame: with persist the grid is one chip-full of
+    // blocks (a multiple of 8, so a block keeps its XCD and the tile map of pixel_of_thread its meaning)
+    for (uint32_t vb = blockIdx.x; vb < nb; vb += gridDim.x) {
+        uint32_t px, py;
+        bool active = pixel_of_thread(V, sh, nb, px, py, vb);
+        bool alive = false;
+        f3 o, d, col; uint32_t rng = 0, pixel = 0;
+        if (active) {
+            pixel = py * V.width + px;
+            f3 d0;
+            ray_gen(V, px, py, o, d0);
+            rng = rt_seed(pixel, sample, seed, stream_id);
+            float jx = rt_rand(rng), jy = rt_rand(rng);
+            d = add(d0, scl(F3(jx, jy, 0.0f), 0.0015f));   // wgsl:184, not renormalised
+            col = F3(1.0f, 1.0f, 1.0f);
+            float4 *acc = accum + pixel;
+            float4 a = *acc; a.w = a.w + 1.0f; *acc = a;   // one more sample for this pixel
+            alive = path_segment<COUNT>(S, flags, stk, o, d, col, rng, acc, c) && max_segments > 1;
+            ++n_primary;
+        }
+        uint32_t slot = queue_slot(counters + qo_ctr, alive);
+        if (alive) {
+            qo.ox[slot] = o.x; qo.oy[slot] = o.y; qo.oz[slot] = o.z;
+            qo.dx[slot] = d.x; qo.dy[slot] = d.y; qo.dz[slot] = d.z;
+            qo.cr[slot] = col.x; qo.cg[slot] = col.y; qo.cb[slot] = col.z;
+            qo.rng[slot] = rng; qo.pixel[slot] = pixel;
+        }
     }
-    wave_count(counters + RT_CNT_PRIMARY, active);
-    uint32_t slot = queue_slot(counters + qo_ctr, alive);
-    if (alive) {
-        qo.ox[slot] = o.x; qo.oy[slot] = o.y; qo.oz[slot] = o.z;
-        qo.dx[slot] = d.x; qo.dy[slot] = d.y; qo.dz[slot] = d.z;
-        qo.cr[slot] = col.x; qo.cg[slot] = col.y; qo.cb[slot] = col.z;
-        qo.rng[slot] = rng; qo.pixel[slot] = pixel;
-    }
+    wave_sum(counters + RT_CNT_PRIMARY, n_primary);
     if (COUNT) {
         wave_sum(counters + RT_CNT_NODES, c.nodes);
         wave_sum(counters + RT_CNT_TRIS, c.tris);
@@ -892,35 +901,42 @@ __global__ __launch_bounds__(RT_BLOCK, RT_MIN_WAVES) void k_path_start(RtSceneDe
     }
 }
 
+// persist != 0: one chip-full of blocks strides over the queue in 256-path chunks: later bounces hold few
+// paths, and a grid sized for the frame would spend its time dispatching empty blocks.  (Taking 64 paths at
+// a time from one work counter instead was 11 % slower on the 10 M-triangle scene.)
 template <bool COUNT>
 __global__ __launch_bounds__(RT_BLOCK, RT_MIN_WAVES) void k_path_bounce(RtSceneDev S, uint32_t flags, int is_last,
                                                           float4 *__restrict__ accum, RtPathQueue qi, RtPathQueue qo,
                                                           unsigned long long *__restrict__ counters, int qi_ctr,
-                                                          int qo_ctr) {
+                                                          int qo_ctr, uint32_t persist) {
     __shared__ int s_stack[RT_STACK_LDS * RT_BLOCK];
     int *stk = s_stack + threadIdx.x;
-    uint32_t n = (uint32_t)counters[qi_ctr];
-    uint32_t i = blockIdx.x * RT_BLOCK + threadIdx.x;
-    if (blockIdx.x * RT_BLOCK >= n) return;            // whole block past the queue end
-    bool active = i < n;
+    const uint32_t n = (uint32_t)counters[qi_ctr];
     Cnt c; c.nodes = 0; c.tris = 0; c.meshes = 0; c.wnodes = 0; c.wtris = 0; c.walive = 0;
-    bool alive = false;
-    f3 o, d, col; uint32_t rng = 0, pixel = 0;
-    if (active) {
-        o = F3(qi.ox[i], qi.oy[i], qi.oz[i]);
-        d = F3(qi.dx[i], qi.dy[i], qi.dz[i]);
-        col = F3(qi.cr[i], qi.cg[i], qi.cb[i]);
-        rng = qi.rng[i]; pixel = qi.pixel[i];
-        alive = path_segment<COUNT>(S, flags, stk, o, d, col, rng, accum + pixel, c) && !is_last;
+    uint32_t n_bounce = 0;
+    (void)persist;
+    for (uint32_t vb = blockIdx.x; vb * RT_BLOCK < n; vb += gridDim.x) {   // grid-stride over 256-path chunks
+        const uint32_t i = vb * RT_BLOCK + threadIdx.x;
+        bool active = i < n;
+        bool alive = false;
+        f3 o, d, col; uint32_t rng = 0, pixel = 0;
+        if (active) {
+            o = F3(qi.ox[i], qi.oy[i], qi.oz[i]);
+            d = F3(qi.dx[i], qi.dy[i], qi.dz[i]);
+            col = F3(qi.cr[i], qi.cg[i], qi.cb[i]);
+            rng = qi.rng[i]; pixel = qi.pixel[i];
+            alive = path_segment<COUNT>(S, flags, stk, o, d, col, rng, accum + pixel, c) && !is_last;
+            ++n_bounce;
+        }
+        uint32_t slot = queue_slot(counters + qo_ctr, alive);
+        if (alive) {
+            qo.ox[slot] = o.x; qo.oy[slot] = o.y; qo.oz[slot] = o.z;
+            qo.dx[slot] = d.x; qo.dy[slot] = d.y; qo.dz[slot] = d.z;
+            qo.cr[slot] = col.x; qo.cg[slot] = col.y; qo.cb[slot] = col.z;
+            qo.rng[slot] = rng; qo.pixel[slot] = pixel;
+        }
     }
-    wave_count(counters + RT_CNT_BOUNCE, active);
-    uint32_t slot = queue_slot(counters + qo_ctr, alive);
-    if (alive) {
-        qo.ox[slot] = o.x; qo.oy[slot] = o.y; qo.oz[slot] = o.z;
-        qo.dx[slot] = d.x; qo.dy[slot] = d.y; qo.dz[slot] = d.z;
-        qo.cr[slot] = col.x; qo.cg[slot] = col.y; qo.cb[slot] = col.z;
-        qo.rng[slot] = rng; qo.pixel[slot] = pixel;
-    }
+    wave_sum(counters + RT_CNT_BOUNCE, n_bounce);
     if (COUNT) {
         wave_sum(counters + RT_CNT_NODES, c.nodes);
         wave_sum(counters + RT_CNT_TRIS, c.tris);
@@ -1002,25 +1018,30 @@ hipError_t rtk_launch_primary(hipStream_t st, const RtSceneDev &S, const RtViewD
 hipError_t rtk_launch_path_start(hipStream_t st, const RtSceneDev &S, const RtViewDev &V, const RtShardDev &sh,
                                  uint32_t flags, uint32_t sample, uint32_t seed, uint32_t stream_id,
                                  uint32_t max_segments, float *accum, RtPathQueue qout,
-                                 unsigned long long *counters, int qout_counter) {
+                                 unsigned long long *counters, int qout_counter, const RtTune &tune) {
     uint32_t nb = rtk_primary_blocks(sh);
     if (nb == 0) return hipSuccess;
+    uint32_t persist = (flags & (RT_FLAG_STATIC_GRID | RT_FLAG_BRUTE_FORCE)) ? 0u : 1u;
+    uint32_t grid = persist && tune.persist_blocks < nb ? (tune.persist_blocks & ~7u) : nb;
+    if (grid == 0) grid = nb;
     if (flags & RT_FLAG_COUNTERS)
-        hipLaunchKernelGGL(k_path_start<true>, dim3(nb), dim3(RT_BLOCK), 0, st, S, V, sh, nb, flags, sample, seed, stream_id, max_segments, (float4 *)accum, qout, counters, qout_counter);
+        hipLaunchKernelGGL(k_path_start<true>, dim3(grid), dim3(RT_BLOCK), 0, st, S, V, sh, nb, flags, sample, seed, stream_id, max_segments, (float4 *)accum, qout, counters, qout_counter, persist);
     else
-        hipLaunchKernelGGL(k_path_start<false>, dim3(nb), dim3(RT_BLOCK), 0, st, S, V, sh, nb, flags, sample, seed, stream_id, max_segments, (float4 *)accum, qout, counters, qout_counter);
+        hipLaunchKernelGGL(k_path_start<false>, dim3(grid), dim3(RT_BLOCK), 0, st, S, V, sh, nb, flags, sample, seed, stream_id, max_segments, (float4 *)accum, qout, counters, qout_counter, persist);
     return hipGetLastError();
 }
 
 hipError_t rtk_launch_path_bounce(hipStream_t st, const RtSceneDev &S, uint32_t flags, uint32_t capacity,
                                   int is_last, float *accum, RtPathQueue qin, RtPathQueue qout,
-                                  unsigned long long *counters, int qin_counter, int qout_counter) {
+                                  unsigned long long *counters, int qin_counter, int qout_counter, const RtTune &tune) {
     uint32_t nb = (capacity + RT_BLOCK - 1) / RT_BLOCK;
     if (nb == 0) return hipSuccess;
+    uint32_t persist = (flags & (RT_FLAG_STATIC_GRID | RT_FLAG_BRUTE_FORCE)) ? 0u : 1u;
+    uint32_t grid = persist && tune.persist_blocks < nb ? tune.persist_blocks : nb;
     if (flags & RT_FLAG_COUNTERS)
-        hipLaunchKernelGGL(k_path_bounce<true>, dim3(nb), dim3(RT_BLOCK), 0, st, S, flags, is_last, (float4 *)accum, qin, qout, counters, qin_counter, qout_counter);
+        hipLaunchKernelGGL(k_path_bounce<true>, dim3(grid), dim3(RT_BLOCK), 0, st, S, flags, is_last, (float4 *)accum, qin, qout, counters, qin_counter, qout_counter, persist);
     else
-        hipLaunchKernelGGL(k_path_bounce<false>, dim3(nb), dim3(RT_BLOCK), 0, st, S, flags, is_last, (float4 *)accum, qin, qout, counters, qin_counter, qout_counter);
+        hipLaunchKernelGGL(k_path_bounce<false>, dim3(grid), dim3(RT_BLOCK), 0, st, S, flags, is_last, (float4 *)accum, qin, qout, counters, qin_counter, qout_counter, persist);
     return hipGetLastError();
 }
 

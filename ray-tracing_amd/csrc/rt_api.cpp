@@ -36,9 +36,12 @@ struct rt_ctx {
     void *d_nodes = nullptr, *d_recs = nullptr, *d_tris = nullptr, *d_meshes = nullptr, *d_verts = nullptr,
          *d_mats = nullptr, *d_spheres = nullptr, *d_sphere_mats = nullptr;
     rt_bvh_info info{};
-    RtBvhBuildResult bvh_host;            // retained for refits (rt_update_vertices)
+    RtBvhBuildResult bvh_host;            // host copy of the tree (RT_TUNE_HOST_REFIT path)
+    bool bvh_host_stale = false;          // the device tree has been refitted since
     std::vector<rt_triangle> h_tris;      // topology of the uploaded scene
     std::vector<rt_mesh_info> h_meshes;
+    void *d_level_nodes = nullptr;        // node indices grouped by tree level, deepest level first (GPU refit)
+    std::vector<uint32_t> level_count;    // nodes per group, in that order
 
     // view + framebuffers
     bool has_view = false;
@@ -89,7 +92,8 @@ void free_dev(void *&p) { if (p) { (void)hipFree(p); p = nullptr; } }
 void free_scene(rt_ctx *c) {
     free_dev(c->d_nodes); free_dev(c->d_recs); free_dev(c->d_tris);
     free_dev(c->d_meshes); free_dev(c->d_verts); free_dev(c->d_mats);
-    free_dev(c->d_spheres); free_dev(c->d_sphere_mats);
+    free_dev(c->d_spheres); free_dev(c->d_sphere_mats); free_dev(c->d_level_nodes);
+    c->level_count.clear();
     c->has_scene = false;
     std::memset(&c->S, 0, sizeof c->S);
 }
@@ -352,6 +356,24 @@ int rt_upload_scene_ex(rt_ctx *c, const rt_triangle *tris, size_t n_tris, const 
     if ((rc = upload(c, c->d_mats, mats, n_mats)) != RT_OK) return rc;
     if ((rc = upload(c, c->d_spheres, spheres, n_spheres)) != RT_OK) return rc;
     if ((rc = upload(c, c->d_sphere_mats, sphere_mats, n_spheres)) != RT_OK) return rc;
+    {   // tree levels for the GPU refit: depth of every node (children are stored after their parent)
+        const size_t nn = bvh.nodes.size();
+        std::vector<uint32_t> depth(nn, 0), order(nn);
+        uint32_t maxd = 0;
+        for (size_t i = 0; i < nn; ++i) {
+            const RtBvhNode &N = bvh.nodes[i];
+            if (N.child0 >= 0) depth[N.child0] = depth[i] + 1;
+            if (N.child1 >= 0) depth[N.child1] = depth[i] + 1;
+            if (depth[i] > maxd) maxd = depth[i];
+        }
+        std::vector<uint32_t> count(nn ? maxd + 1 : 0, 0), start(nn ? maxd + 2 : 1, 0);
+        for (size_t i = 0; i < nn; ++i) count[maxd - depth[i]]++;              // group 0 = deepest level
+        for (size_t g = 0; g < count.size(); ++g) start[g + 1] = start[g] + count[g];
+        std::vector<uint32_t> fill(start.begin(), start.end());
+        for (size_t i = 0; i < nn; ++i) order[fill[maxd - depth[i]]++] = (uint32_t)i;
+        if ((rc = upload(c, c->d_level_nodes, order.data(), nn)) != RT_OK) return rc;
+        c->level_count = count;
+    }
     HIPCHK(c, hipStreamSynchronize(c->stream));   // host arrays are borrowed for this call only
 
     c->S.nodes = (const RtBvhNode *)c->d_nodes;
@@ -375,6 +397,7 @@ int rt_upload_scene_ex(rt_ctx *c, const rt_triangle *tris, size_t n_tris, const 
     c->h_tris.assign(tris, tris + n_tris);
     c->h_meshes.assign(meshes, meshes + n_meshes);
     c->bvh_host = std::move(bvh);
+    c->bvh_host_stale = false;
     c->has_scene = true;
     c->accum_samples = 0;
     c->coverage_sig = 0;
@@ -392,17 +415,52 @@ int rt_update_vertices(rt_ctx *c, const rt_vertex *verts, size_t n_verts, const 
             return fail(c, RT_ERR_SCENE, "rt_update_vertices: mesh triangle ranges differ from the uploaded scene");
     if (c->bvh_host.dropped)   // triangles left out of the tree at build time could have become valid
         return fail(c, RT_ERR_SCENE, "rt_update_vertices: the built tree dropped non-finite triangles, rebuild with rt_upload_scene");
-    if (!rt_bvh_refit(&c->bvh_host, c->h_tris.data(), verts, 0))
-        return fail(c, RT_ERR_SCENE, "rt_update_vertices: non-finite vertex, rebuild with rt_upload_scene");
     HIPCHK(c, hipSetDevice(c->device));
-    const RtBvhBuildResult &b = c->bvh_host;
-    if (!b.nodes.empty()) HIPCHK(c, hipMemcpyAsync(c->d_nodes, b.nodes.data(), b.nodes.size() * sizeof(RtBvhNode), hipMemcpyHostToDevice, c->stream));
-    if (!b.recs.empty()) HIPCHK(c, hipMemcpyAsync(c->d_recs, b.recs.data(), b.recs.size() * sizeof(RtTriRecord), hipMemcpyHostToDevice, c->stream));
-    if (n_verts) HIPCHK(c, hipMemcpyAsync(c->d_verts, verts, n_verts * sizeof(rt_vertex), hipMemcpyHostToDevice, c->stream));
-    if (n_meshes) HIPCHK(c, hipMemcpyAsync(c->d_meshes, meshes, n_meshes * sizeof(rt_mesh_info), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));   // host arrays are borrowed for this call only
+    double refit_ms = 0.0;
+    if (std::getenv("RT_TUNE_HOST_REFIT")) {
+        // the round's first version, kept for A/B and as the reference the GPU refit is tested against: refit on
+        // the host, then re-upload nodes and records (0.6 GB over PCIe for the 7.2 M-triangle bench scene)
+        if (c->bvh_host_stale) return fail(c, RT_ERR_SCENE, "rt_update_vertices: host refit after a GPU refit needs a rebuild");
+        if (!rt_bvh_refit(&c->bvh_host, c->h_tris.data(), verts, 0))
+            return fail(c, RT_ERR_SCENE, "rt_update_vertices: non-finite vertex, rebuild with rt_upload_scene");
+        const RtBvhBuildResult &b = c->bvh_host;
+        if (!b.nodes.empty()) HIPCHK(c, hipMemcpyAsync(c->d_nodes, b.nodes.data(), b.nodes.size() * sizeof(RtBvhNode), hipMemcpyHostToDevice, c->stream));
+        if (!b.recs.empty()) HIPCHK(c, hipMemcpyAsync(c->d_recs, b.recs.data(), b.recs.size() * sizeof(RtTriRecord), hipMemcpyHostToDevice, c->stream));
+        if (n_verts) HIPCHK(c, hipMemcpyAsync(c->d_verts, verts, n_verts * sizeof(rt_vertex), hipMemcpyHostToDevice, c->stream));
+        if (n_meshes) HIPCHK(c, hipMemcpyAsync(c->d_meshes, meshes, n_meshes * sizeof(rt_mesh_info), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));   // host arrays are borrowed for this call only
+        refit_ms = b.build_ms;
+    } else {
+        // GPU refit: only the moved data (T3 vertices, T2 mesh boxes) crosses PCIe; records are re-baked and the
+        // boxes refitted on the device, one launch per tree level, deepest first.  A non-finite vertex is refused
+        // up front (the tree would have to drop that triangle), before anything on the device changes.
+        for (size_t i = 0; i < n_verts; ++i)
+            if (!std::isfinite(verts[i].pos[0]) || !std::isfinite(verts[i].pos[1]) || !std::isfinite(verts[i].pos[2])) {
+                bool used = false;   // only vertices some triangle of the tree uses matter (as in the host refit)
+                for (const rt_triangle &T : c->h_tris) if (T.indices[0] == i || T.indices[1] == i || T.indices[2] == i) { used = true; break; }
+                if (used) return fail(c, RT_ERR_SCENE, "rt_update_vertices: non-finite vertex, rebuild with rt_upload_scene");
+            }
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        HIPCHK(c, hipEventCreate(&e0)); HIPCHK(c, hipEventCreate(&e1));
+        if (n_verts) HIPCHK(c, hipMemcpyAsync(c->d_verts, verts, n_verts * sizeof(rt_vertex), hipMemcpyHostToDevice, c->stream));
+        if (n_meshes) HIPCHK(c, hipMemcpyAsync(c->d_meshes, meshes, n_meshes * sizeof(rt_mesh_info), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipEventRecord(e0, c->stream));
+        size_t off = 0;
+        for (uint32_t cnt : c->level_count) {
+            HIPCHK(c, rtk_launch_refit_level(c->stream, (RtBvhNode *)c->d_nodes, (RtTriRecord *)c->d_recs, (const rt_triangle *)c->d_tris,
+                                             (const rt_vertex *)c->d_verts, (const uint32_t *)c->d_level_nodes + off, cnt));
+            off += cnt;
+        }
+        HIPCHK(c, hipEventRecord(e1, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));   // host arrays are borrowed for this call only
+        float ms = 0.0f;
+        HIPCHK(c, hipEventElapsedTime(&ms, e0, e1));
+        (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+        refit_ms = ms;
+        c->bvh_host_stale = true;
+    }
     c->h_meshes.assign(meshes, meshes + n_meshes);
-    c->info.build_ms = b.build_ms;
+    c->info.build_ms = refit_ms;
     c->info.n_refits += 1;
     c->accum_dirty = true;                        // geometry moved: accumulation restarts
     return RT_OK;

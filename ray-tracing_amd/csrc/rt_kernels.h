@@ -34,6 +34,10 @@ hipError_t rtk_launch_path_bounce(hipStream_t st, const RtSceneDev &S, uint32_t 
                                   int is_last, float *accum, RtPathQueue qin, RtPathQueue qout,
                                   unsigned long long *counters, int qin_counter, int qout_counter, const RtTune &tune);
 
+// f1: refit one tree level (nodes listed in level_nodes) from the vertices now in `verts`; leaf records re-baked.
+hipError_t rtk_launch_refit_level(hipStream_t st, RtBvhNode *nodes, RtTriRecord *recs, const rt_triangle *tris,
+                                  const rt_vertex *verts, const uint32_t *level_nodes, uint32_t n);
+
 hipError_t rtk_launch_resolve(hipStream_t st, const float *accum, float *rgba, size_t n_px, float inv_unused,
                               uint32_t total_samples);
 hipError_t rtk_launch_encode_bgra8(hipStream_t st, const float *rgba, uint8_t *bgra, size_t n_px);

@@ -944,6 +944,70 @@ __global__ __launch_bounds__(RT_BLOCK, RT_MIN_WAVES) void k_path_bounce(RtSceneD
     }
 }
 
+// ---- f1 refit on the GPU: vertices moved, topology unchanged -----------------------------
+// One launch per tree level, deepest first (children are finished before their parent reads them; a kernel
+// boundary on one stream is the only ordering needed).  A thread owns one node of the level: for a LEAF child
+// it re-bakes the child's records from the new vertices (a, ab, ac: the values ray_tracing.wgsl:122-123
+// computes) and boxes them with the builder's padding rule; for an INNER child it takes the union of that
+// child's two boxes.  Same float operations as the host refit (bvh_build.cpp), so the boxes are bit-identical.
+__device__ __forceinline__ void box_of_child(int32_t code, RtBvhNode *nodes, RtTriRecord *recs, const rt_triangle *tris,
+                                             const rt_vertex *verts, float lo[3], float hi[3]) {
+    for (int k = 0; k < 3; ++k) { lo[k] = RT_INF; hi[k] = -RT_INF; }
+    if (code >= 0) {
+        const RtBvhNode &C = nodes[code];
+        if (C.child0 != RT_CHILD_NONE) for (int k = 0; k < 3; ++k) { lo[k] = fminf(lo[k], C.lo0[k]); hi[k] = fmaxf(hi[k], C.hi0[k]); }
+        if (C.child1 != RT_CHILD_NONE) for (int k = 0; k < 3; ++k) { lo[k] = fminf(lo[k], C.lo1[k]); hi[k] = fmaxf(hi[k], C.hi1[k]); }
+        return;
+    }
+    uint32_t v = (uint32_t)(~code), first = v >> 3, cnt = (v & 7u) + 1u;
+    for (uint32_t i = first; i < first + cnt; ++i) {
+        RtTriRecord &R = recs[i];
+        float blo[3], bhi[3], amax = 0.0f;
+        if (R.mesh == RT_REC_SPHERE) {           // spheres do not move in a vertex update
+            float r = fabsf(R.abx);
+            for (int k = 0; k < 3; ++k) amax = fmaxf(amax, fmaxf(fabsf(R.a[k] - r), fabsf(R.a[k] + r)));
+            float pad = 2e-5f * amax + 1e-30f;
+            for (int k = 0; k < 3; ++k) { blo[k] = R.a[k] - r - pad; bhi[k] = R.a[k] + r + pad; }
+        } else {
+            rt_triangle T = tris[R.tri];
+            const float *a = verts[T.indices[0]].pos, *b = verts[T.indices[1]].pos, *c = verts[T.indices[2]].pos;
+            float A[3] = {a[0], a[1], a[2]}, B[3] = {b[0], b[1], b[2]}, C[3] = {c[0], c[1], c[2]};
+            for (int k = 0; k < 3; ++k) {
+                blo[k] = fminf(A[k], fminf(B[k], C[k]));
+                bhi[k] = fmaxf(A[k], fmaxf(B[k], C[k]));
+                amax = fmaxf(amax, fmaxf(fabsf(blo[k]), fabsf(bhi[k])));
+            }
+            float pad = 1e-5f * amax + 1e-30f;    // same padding rule as the build
+            for (int k = 0; k < 3; ++k) { blo[k] -= pad; bhi[k] += pad; }
+            R.a[0] = A[0]; R.a[1] = A[1]; R.a[2] = A[2];
+            R.abx = B[0] - A[0]; R.aby = B[1] - A[1]; R.abz = B[2] - A[2];
+            R.acx = C[0] - A[0]; R.acy = C[1] - A[1]; R.acz = C[2] - A[2];
+        }
+        for (int k = 0; k < 3; ++k) { lo[k] = fminf(lo[k], blo[k]); hi[k] = fmaxf(hi[k], bhi[k]); }
+    }
+}
+__global__ void k_refit_level(RtBvhNode *nodes, RtTriRecord *recs, const rt_triangle *__restrict__ tris,
+                              const rt_vertex *__restrict__ verts, const uint32_t *__restrict__ level_nodes, uint32_t n) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    RtBvhNode &N = nodes[level_nodes[i]];
+    float lo[3], hi[3];
+    if (N.child0 != RT_CHILD_NONE) {
+        box_of_child(N.child0, nodes, recs, tris, verts, lo, hi);
+        for (int k = 0; k < 3; ++k) { N.lo0[k] = lo[k]; N.hi0[k] = hi[k]; }
+    }
+    if (N.child1 != RT_CHILD_NONE) {
+        box_of_child(N.child1, nodes, recs, tris, verts, lo, hi);
+        for (int k = 0; k < 3; ++k) { N.lo1[k] = lo[k]; N.hi1[k] = hi[k]; }
+    }
+}
+hipError_t rtk_launch_refit_level(hipStream_t st, RtBvhNode *nodes, RtTriRecord *recs, const rt_triangle *tris,
+                                  const rt_vertex *verts, const uint32_t *level_nodes, uint32_t n) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_refit_level, dim3((n + 255) / 256), dim3(256), 0, st, nodes, recs, tris, verts, level_nodes, n);
+    return hipGetLastError();
+}
+
 // ---- A8 resolve: light / f32(samples) (ray_tracing.wgsl:212) ----------------------------------------
 __global__ void k_resolve(const float4 *__restrict__ accum, float4 *__restrict__ rgba, size_t n, float ns) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;

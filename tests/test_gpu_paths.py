@@ -186,6 +186,16 @@ def test_update_vertices_refit_matches_a_rebuild_and_rejects_other_topologies():
         assert bitwise_equal(ctx.read_prim_ids(), prim_o) and bitwise_equal(ctx.read_hit_t(), t_o)
         assert bitwise_equal(ctx.read_radiance(), rgba_o)
         assert ctx.bvh_info().n_refits == 1
+        # the GPU refit (one launch per tree level) gives the boxes and records of the host refit, bit for bit
+        _, nodes_h, recs_h = rt.host_bvh_build(scene, threads=2, refit_to=moved)
+        nodes_g, recs_g = ctx.read_bvh()
+        assert bitwise_equal(nodes_g, nodes_h) and bitwise_equal(recs_g, recs_h)
+        bad = rt.Scene(scene.triangles, moved.meshes, moved.vertices.copy(), scene.materials)
+        bad.vertices["pos"][int(moved.triangles["indices"][0][0])] = np.nan       # a non-finite vertex needs a rebuild
+        with pytest.raises(rt.RtError) as e:
+            ctx.update_vertices(bad)
+        assert e.value.status == rt.RT_ERR_SCENE
+        assert bitwise_equal(ctx.read_bvh()[0], nodes_h)                          # ... and left the tree untouched
         fewer = rt.Scene(scene.triangles, scene.meshes[:-1], scene.vertices, scene.materials)
         with pytest.raises(rt.RtError) as e:
             ctx.update_vertices(fewer)

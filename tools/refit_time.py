@@ -1,0 +1,16 @@
+"""Experiment script (GPU): rt_update_vertices on the bench scene, GPU refit vs host refit + re-upload. Not a test."""
+import os, sys, time
+_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [_ROOT]
+import numpy as np, ray_tracing_amd as rt
+app = rt.App(); app.spawn_sphere_field(10000, 0x5EED0002, 5); app.camera_frame_scene(1.0); app.camera_set_target(1920, 1080)
+sc = app.prepare_meshinfo(); m, p = app.camera_view()
+moved = rt.Scene(sc.triangles, sc.meshes.copy(), sc.vertices.copy(), sc.materials)
+moved.vertices["pos"][:, 1] += 0.25; moved.meshes["aabb_min"][:, 1] += 0.25; moved.meshes["aabb_max"][:, 1] += 0.25
+for mode in ("gpu", "host"):
+    if mode == "host": os.environ["RT_TUNE_HOST_REFIT"] = "1"
+    ctx = rt.Context(0); ctx.upload_scene(sc); ctx.set_view(m, p, 1920, 1080)
+    t0 = time.perf_counter(); ctx.update_vertices(moved); dt = time.perf_counter() - t0
+    ctx.render(flags=rt.FLAG_SHADOW); prim = ctx.read_prim_ids()
+    print(mode, "rt_update_vertices wall %.1f ms, refit itself %.2f ms" % (dt * 1e3, ctx.bvh_info().build_ms), "hash", int(prim.astype(np.uint64).sum()), flush=True)
+    ctx.close()

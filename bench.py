@@ -184,7 +184,12 @@ def main():
         ctx.render(flags=f, **shard)
         if tiles:
             frame_t.copy_(rad_t)
-            dist.all_reduce(frame_t, op=dist.ReduceOp.SUM)   # other ranks' tiles are zero here: sum == gather
+            if dist.get_backend() == "gloo":                  # rehearsal only: gloo reduces host tensors
+                host = frame_t.cpu()
+                dist.all_reduce(host, op=dist.ReduceOp.SUM)
+                frame_t.copy_(host)
+            else:
+                dist.all_reduce(frame_t, op=dist.ReduceOp.SUM)   # other ranks' tiles are zero here: sum == gather
 
     for _ in range(args.warmup):
         step(flags)

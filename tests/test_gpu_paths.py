@@ -304,3 +304,44 @@ def test_soup_1m_triangles_sampled_parity():
     acc = ctx.read_accumulation()
     assert np.all(acc[..., 3] == 1.0) and np.isfinite(acc).all()
     ctx.close()
+
+
+def test_deep_tree_uses_the_private_part_of_the_stack():
+    """600 k parallel triangles stacked along the view direction: the tree is deeper than the 16 stack levels a lane
+    keeps in LDS, and a ray that runs down the stack pushes a far child on every level, so the levels beyond 16 (private
+    array behind the LDS column) are exercised in every kernel variant."""
+    n, W, H = 600_000, 32, 18
+    z = -(np.arange(n, dtype=np.float32) * np.float32(0.01))
+    verts = np.zeros(3 * n, rt.VERTEX)
+    base = np.array([(-4.0, -3.0), (4.0, -3.0), (0.0, 5.0)], np.float32)      # counter-clockwise seen from +z: front face
+    verts["pos"][:, :2] = np.tile(base, (n, 1))
+    verts["pos"][:, 2] = np.repeat(z, 3)
+    verts["norm"][:] = (0.0, 0.6, 0.8)
+    tris = np.zeros(n, rt.TRIANGLE); tris["indices"] = np.arange(3 * n, dtype=np.uint32).reshape(n, 3)
+    meshes = np.zeros(1, rt.MESH_INFO)
+    meshes["first_tri"], meshes["tri_count"], meshes["material"] = 0, n, 0
+    meshes["aabb_min"][0], meshes["aabb_max"][0] = (-5, -4, float(z[-1]) - 1), (5, 6, 1)
+    mats = np.zeros(1, rt.MATERIAL); mats["color"][0] = (0.9, 0.5, 0.1, 1.0)
+    scene = rt.Scene(tris, meshes, verts, mats)
+    app = rt.App()
+    app.camera_look_at((0.3, 0.2, 6.0), (0.0, 0.5, -50.0), (0, 1, 0))
+    app.camera_set_target(W, H)
+    m, p = app.camera_view()
+    rgba_o, prim_o, t_o, _ = orc.render_primary(oracle_scene(scene), orc.make_view(m, p, W, H), orc.FLAG_SHADOW, threads=16)
+    assert (prim_o == 0).sum() > 100                                         # the front triangle is what the rays see
+    with rt.Context(0) as ctx:
+        ctx.upload_scene(scene)
+        assert ctx.bvh_info().max_depth > 16
+        ctx.set_view(m, p, W, H)
+        for extra in (0, rt.FLAG_STATIC_GRID, rt.FLAG_WAVE_TRAVERSAL):
+            assert ctx.render(flags=rt.FLAG_SHADOW | extra) == rt.RT_OK
+            assert bitwise_equal(ctx.read_prim_ids(), prim_o) and bitwise_equal(ctx.read_hit_t(), t_o)
+            assert bitwise_equal(ctx.read_radiance(), rgba_o)
+        # rays that look at the BACK of the stack hit nothing and have to walk the whole depth of the tree
+        app.camera_look_at((0.3, 0.2, -6100.0), (0.0, 0.5, 0.0), (0, 1, 0))
+        m2, p2 = app.camera_view()
+        ctx.set_view(m2, p2, W, H)
+        for extra in (0, rt.FLAG_STATIC_GRID):
+            assert ctx.render(flags=extra | rt.FLAG_COUNTERS) == rt.RT_OK
+            assert (ctx.read_prim_ids() == 0xFFFFFFFF).all()
+            assert ctx.counters().tri_tests > 10_000                         # they walked into the stack, leaf after leaf

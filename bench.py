@@ -7,7 +7,9 @@ ray per pixel + one shadow ray per hit.  A step = one frame through rt_render (C
 N>1: scene replicated, one process per GPU; --mode frames (default) gives every rank its own
 camera on an orbit (weak scaling, no data-path collective); --mode tiles shards ONE frame by
 64x64 screen tiles round-robin over the ranks and combines with one RCCL all_reduce(sum) of the
-zero-initialised radiance buffers (strong scaling).
+zero-initialised radiance buffers (strong scaling); --mode samples (path-tracing workloads) gives every
+rank its own sample slice of ONE frame and combines the accumulation buffers with one all_reduce(sum)
+(weak scaling in samples: SURVEY 8e, BASELINE.json configs[4]).
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` and
 `cpu_baseline` objects.  Never reads /root/reference.
@@ -107,7 +109,7 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="sphere_field_10k_1080p_primary_shadow", choices=sorted(WORKLOADS))
-    ap.add_argument("--mode", default="frames", choices=["frames", "tiles"])
+    ap.add_argument("--mode", default="frames", choices=["frames", "tiles", "samples"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--extra-flags", type=lambda v: int(v, 0), default=0,
@@ -139,7 +141,10 @@ def main():
 
     app, W, H = build_app(rt, args.workload, rank, world)
     tiles = args.mode == "tiles" and world > 1
-    if world > 1 and not tiles:
+    samples = args.mode == "samples" and world > 1
+    if samples and len(WORKLOADS[args.workload]) <= 5:
+        raise SystemExit("--mode samples needs a path-tracing workload")
+    if world > 1 and not tiles and not samples:
         orbit_camera(app, rank, world)
     scene = app.prepare_meshinfo()            # P1: scene extraction (host)
     if WORKLOADS[args.workload][0] == "field_analytic":
@@ -158,6 +163,8 @@ def main():
     shard = dict(shard_rank=rank, shard_count=world, tile_size=64) if tiles else {}
     if spp:
         shard.update(spp=spp, max_segments=segs, seed=1, stream_id=rank)
+    if samples:   # one frame, rank r renders samples [r*spp, (r+1)*spp) of the same RNG stream
+        shard.update(sample_first=rank * spp, stream_id=0)
 
     # instrumented launch (same view): counted node visits / triangle tests for the roofline
     ctx.render(flags=flags | rt.FLAG_COUNTERS, **shard)
@@ -180,8 +187,24 @@ def main():
         rad_t = torch.as_tensor(_Ptr(), device=f"cuda:{local_rank}")
         frame_t = torch.empty_like(rad_t)   # combined frame; the library's buffer keeps only this rank's tiles
 
+    acc_t = None
+    if samples:
+        _, _, d_acc = ctx.device_buffers()
+
+        class _PtrA:
+            __cuda_array_interface__ = dict(shape=(H * W * 4,), typestr="<f4", data=(d_acc, False), version=2)
+        acc_t = torch.as_tensor(_PtrA(), device=f"cuda:{local_rank}")
+
     def step(f):
         ctx.render(flags=f, **shard)
+        if samples:
+            if dist.get_backend() == "gloo":                  # rehearsal only: gloo reduces host tensors
+                host = acc_t.cpu()
+                dist.all_reduce(host, op=dist.ReduceOp.SUM)
+                acc_t.copy_(host)
+            else:
+                dist.all_reduce(acc_t, op=dist.ReduceOp.SUM)  # running sums of all ranks' sample slices
+            ctx.resolve_accumulation(spp * world)             # radiance = sum / total samples, on the device
         if tiles:
             frame_t.copy_(rad_t)
             if dist.get_backend() == "gloo":                  # rehearsal only: gloo reduces host tensors
@@ -239,7 +262,8 @@ def main():
                        "triangles": int(info.n_triangles), "bvh_nodes": int(info.n_nodes),
                        "rays_per_step_rank0": int(rays_step),
                        "primary_hit_fraction": round(hits / max(cnt.rays_primary, 1), 4), "camera_radii": CAMERA_RADII,
-                       "parallelism": ("tiles64-roundrobin+allreduce" if tiles else f"frames-dp{world}")},
+                       "parallelism": ("tiles64-roundrobin+allreduce" if tiles else
+                                       (f"sample-slices{world}+allreduce" if samples else f"frames-dp{world}"))},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "kernel": ("k_path_start+k_path_bounce (whole frame)" if spp else "k_stream<false>"),

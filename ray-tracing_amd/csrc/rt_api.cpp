@@ -192,7 +192,9 @@ int rt_create(int device_ordinal, rt_ctx **out) {
             long v = std::atol(e);
             return (v < (long)lo || v > (long)hi) ? dflt : (uint32_t)v;
         };
-        c->tune.persist_blocks = (uint32_t)prop.multiProcessorCount * env("RT_TUNE_BLOCKS_PER_CU", 8, 1, 16);
+        c->tune.cus = (uint32_t)prop.multiProcessorCount;
+        c->tune.persist_blocks = c->tune.cus * 8;
+        c->tune.blocks_per_cu = env("RT_TUNE_BLOCKS_PER_CU", 0, 0, 8);
         c->tune.refill_min = env("RT_TUNE_REFILL_MIN", 64, 1, 64);
         c->tune.finish_min = env("RT_TUNE_FINISH_MIN", 64, 1, 64);
         c->tune.vote_node = env("RT_TUNE_VOTE_NODE", 3, 1, 64);

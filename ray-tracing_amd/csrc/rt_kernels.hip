@@ -1072,8 +1072,17 @@ hipError_t rtk_launch_primary(hipStream_t st, const RtSceneDev &S, const RtViewD
     if (!packet && !(flags & RT_FLAG_STATIC_GRID) && !(flags & RT_FLAG_BRUTE_FORCE)) {
         // persistent kernel: a grid that fills the chip once; blocks that start late find the queues
         // empty and exit, so no residency assumption is made
+        // Waves in flight: a tree that misses the caches needs all 8 waves per SIMD to hide the misses (85 MB of nodes
+        // and records: 0.74 ms with 8 blocks per CU, 0.95 with 3); a tree that one XCD's 4 MiB L2 holds does not, and
+        // fewer waves each run faster and leave a shorter tail at the end of the frame (the reference's default scene
+        // at 1080p: 0.27 ms with 3 blocks per CU, 0.37 with 8; tools/occupancy_sweep.py).
+        uint32_t per_cu = tune.blocks_per_cu;
+        if (per_cu == 0) {
+            size_t tree = (size_t)S.n_nodes * sizeof(RtBvhNode) + (size_t)S.n_recs * sizeof(RtTriRecord);
+            per_cu = tree <= ((size_t)4 << 20) ? 3u : (tree <= ((size_t)16 << 20) ? 5u : 8u);
+        }
         uint32_t need = (sh.n_owned * sh.tile * sh.tile + RT_BLOCK - 1) / RT_BLOCK;
-        uint32_t grid = tune.persist_blocks < need ? tune.persist_blocks : need;
+        uint32_t grid = tune.cus * per_cu < need ? tune.cus * per_cu : need;
         if (grid == 0) return hipSuccess;
         if (count) hipLaunchKernelGGL((k_stream<true>), dim3(grid), dim3(RT_BLOCK), 0, st, S, V, sh, flags, tune.refill_min, tune.finish_min, tune.vote_node, tune.vote_tri, (float4 *)rgba, prim, t, counters);
         else hipLaunchKernelGGL((k_stream<false>), dim3(grid), dim3(RT_BLOCK), 0, st, S, V, sh, flags, tune.refill_min, tune.finish_min, tune.vote_node, tune.vote_tri, (float4 *)rgba, prim, t, counters);

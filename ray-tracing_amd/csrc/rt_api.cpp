@@ -199,6 +199,7 @@ int rt_create(int device_ordinal, rt_ctx **out) {
         c->tune.finish_min = env("RT_TUNE_FINISH_MIN", 64, 1, 64);
         c->tune.vote_node = env("RT_TUNE_VOTE_NODE", 3, 1, 64);
         c->tune.vote_tri = env("RT_TUNE_VOTE_TRI", 1, 1, 64);
+        c->tune.uni_min = env("RT_TUNE_UNI_MIN", 16, 1, 65);
     }
     int rc = RT_OK;
     do {

@@ -21,6 +21,7 @@ struct RtTune {
     uint32_t refill_min;       // idle lanes in a wave that trigger a refill (64 = whole 8x8 blocks only)
     uint32_t finish_min;       // ended rays in a wave that trigger a hand-over
     uint32_t vote_node, vote_tri;   // relative issue cost of a node step / a triangle step (phase vote)
+    uint32_t uni_min;          // lanes that must share one node for the scalar node fetch (65 = never)
 };
 hipError_t rtk_launch_primary(hipStream_t st, const RtSceneDev &S, const RtViewDev &V, const RtShardDev &sh,
                               uint32_t flags, float *rgba, uint32_t *prim, float *t,

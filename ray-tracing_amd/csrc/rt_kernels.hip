@@ -547,10 +547,37 @@ __device__ __forceinline__ bool pixel_of_region(const RtViewDev &V, const RtShar
     return xx < V.vw && yy < V.vh;
 }
 
+// One node step: the two child boxes of the fetched node against the lane's ray, then descend / push / pop.
+// Q: float4 (per-lane vector fetch) or q4 (one scalar fetch for the whole wave, operands in SGPRs).
+template <class Q>
+__device__ __forceinline__ void node_decide(Q q0, Q q1, Q q2, Q q3, f3 o, f3 inv, float t, int &cur, int &sp, lds_int *stk,
+                                            prv_int *ovf) {
+    const float limit = t * 1.00001f;   // relaxed bound: near-ties are still visited, seq decides
+    float ax0 = (q0.x - o.x) * inv.x, ax1 = (q0.w - o.x) * inv.x;
+    float ay0 = (q0.y - o.y) * inv.y, ay1 = (q1.x - o.y) * inv.y;
+    float az0 = (q0.z - o.z) * inv.z, az1 = (q1.y - o.z) * inv.z;
+    float bx0 = (q1.z - o.x) * inv.x, bx1 = (q2.y - o.x) * inv.x;
+    float by0 = (q1.w - o.y) * inv.y, by1 = (q2.z - o.y) * inv.y;
+    float bz0 = (q2.x - o.z) * inv.z, bz1 = (q2.w - o.z) * inv.z;
+    float tmin0 = fmaxf(fmaxf(fminf(ax0, ax1), fminf(ay0, ay1)), fminf(az0, az1));
+    float tmax0 = fminf(fminf(fmaxf(ax0, ax1), fmaxf(ay0, ay1)), fmaxf(az0, az1));
+    float tmin1 = fmaxf(fmaxf(fminf(bx0, bx1), fminf(by0, by1)), fminf(bz0, bz1));
+    float tmax1 = fminf(fminf(fmaxf(bx0, bx1), fmaxf(by0, by1)), fmaxf(bz0, bz1));
+    tmax0 *= 1.0000005f; tmax1 *= 1.0000005f;   // robust slab test (2 ulp)
+    bool h0 = tmin0 <= tmax0 && tmax0 >= 0.0f && tmin0 <= limit;
+    bool h1 = tmin1 <= tmax1 && tmax1 >= 0.0f && tmin1 <= limit;
+    int c0 = __float_as_int(q3.x), c1 = __float_as_int(q3.y);
+    bool both = h0 && h1;
+    bool swap = tmin1 < tmin0;
+    if (both) stack_push(sp, stk, ovf, swap ? c0 : c1);
+    if (h0 || h1) cur = (both ? swap : h1) ? c1 : c0;
+    else cur = stack_pop(sp, stk, ovf);
+}
+
 template <bool COUNT>
 __global__ __launch_bounds__(RT_BLOCK, RT_MIN_WAVES) void k_stream(
     RtSceneDev S_, RtViewDev V_, RtShardDev sh_, uint32_t flags, uint32_t refill_min, uint32_t finish_min,
-    uint32_t vote_node, uint32_t vote_tri, float4 *__restrict__ rgba, uint32_t *__restrict__ prim,
+    uint32_t vote_node, uint32_t vote_tri, uint32_t uni_min, float4 *__restrict__ rgba, uint32_t *__restrict__ prim,
     float *__restrict__ tout, unsigned long long *__restrict__ counters) {
     __shared__ int s_stack[RT_STACK_LDS * RT_BLOCK];
     // what only the hand-over code reads lives in LDS, not in ~60 SGPRs that the hot loop would spill
@@ -678,30 +705,25 @@ __global__ __launch_bounds__(RT_BLOCK, RT_MIN_WAVES) void k_stream(
             const uint32_t n_node = (uint32_t)__builtin_popcountll(m_node);
             const uint32_t n_leaf = 64u - n_done - n_node;
             if (n_node * vote_tri >= n_leaf * vote_node) {
-                if (cur >= 0) {
+                // Every lane that takes this step holds the SAME node in 22-79 % of the node trips (the top of the tree,
+                // walked in lockstep): then ONE scalar load brings the node into SGPRs for the whole wave instead of four
+                // vector loads per lane -- the vector-memory front end is as busy as the VALU in this kernel.
+                const int u0 = __builtin_amdgcn_readlane(cur, __builtin_ctzll(m_node));
+                const bool uniform = n_node >= uni_min && __ballot(cur >= 0 && cur != u0) == 0ull;
+                if (uniform) {
+                    typedef __attribute__((address_space(4))) const float cfloat;
+                    cfloat *sp_ = (cfloat *)(const void *)(nodes + u0);
+                    q4 q0 = {sp_[0], sp_[1], sp_[2], sp_[3]}, q1 = {sp_[4], sp_[5], sp_[6], sp_[7]};
+                    q4 q2 = {sp_[8], sp_[9], sp_[10], sp_[11]}, q3 = {sp_[12], sp_[13], sp_[14], sp_[15]};
+                    if (cur >= 0) {
+                        if (COUNT) { c.nodes++; if (lane == (uint32_t)__builtin_ctzll(m_node)) { c.wnodes++; c.walive += n_node + n_leaf; } }
+                        node_decide(q0, q1, q2, q3, o, inv, t, cur, sp, stk, ovf);
+                    }
+                } else if (cur >= 0) {
                     const float4 *p = reinterpret_cast<const float4 *>(nodes + cur);
                     float4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3];
                     if (COUNT) { c.nodes++; if (lane == (uint32_t)__builtin_ctzll(m_node)) { c.wnodes++; c.walive += n_node + n_leaf; } }
-                    const float limit = t * 1.00001f;   // relaxed bound: near-ties are still visited, seq decides
-                    float ax0 = (q0.x - o.x) * inv.x, ax1 = (q0.w - o.x) * inv.x;
-                    float ay0 = (q0.y - o.y) * inv.y, ay1 = (q1.x - o.y) * inv.y;
-                    float az0 = (q0.z - o.z) * inv.z, az1 = (q1.y - o.z) * inv.z;
-                    float bx0 = (q1.z - o.x) * inv.x, bx1 = (q2.y - o.x) * inv.x;
-                    float by0 = (q1.w - o.y) * inv.y, by1 = (q2.z - o.y) * inv.y;
-                    float bz0 = (q2.x - o.z) * inv.z, bz1 = (q2.w - o.z) * inv.z;
-                    float tmin0 = fmaxf(fmaxf(fminf(ax0, ax1), fminf(ay0, ay1)), fminf(az0, az1));
-                    float tmax0 = fminf(fminf(fmaxf(ax0, ax1), fmaxf(ay0, ay1)), fmaxf(az0, az1));
-                    float tmin1 = fmaxf(fmaxf(fminf(bx0, bx1), fminf(by0, by1)), fminf(bz0, bz1));
-                    float tmax1 = fminf(fminf(fmaxf(bx0, bx1), fmaxf(by0, by1)), fmaxf(bz0, bz1));
-                    tmax0 *= 1.0000005f; tmax1 *= 1.0000005f;   // robust slab test (2 ulp)
-                    bool h0 = tmin0 <= tmax0 && tmax0 >= 0.0f && tmin0 <= limit;
-                    bool h1 = tmin1 <= tmax1 && tmax1 >= 0.0f && tmin1 <= limit;
-                    int c0 = __float_as_int(q3.x), c1 = __float_as_int(q3.y);
-                    bool both = h0 && h1;
-                    bool swap = tmin1 < tmin0;
-                    if (both) stack_push(sp, stk, ovf, swap ? c0 : c1);
-                    if (h0 || h1) cur = (both ? swap : h1) ? c1 : c0;
-                    else cur = stack_pop(sp, stk, ovf);
+                    node_decide(q0, q1, q2, q3, o, inv, t, cur, sp, stk, ovf);
                 }
             } else {
                 if (cur < 0 && cur != RT_DONE) {
@@ -1084,8 +1106,8 @@ hipError_t rtk_launch_primary(hipStream_t st, const RtSceneDev &S, const RtViewD
         uint32_t need = (sh.n_owned * sh.tile * sh.tile + RT_BLOCK - 1) / RT_BLOCK;
         uint32_t grid = tune.cus * per_cu < need ? tune.cus * per_cu : need;
         if (grid == 0) return hipSuccess;
-        if (count) hipLaunchKernelGGL((k_stream<true>), dim3(grid), dim3(RT_BLOCK), 0, st, S, V, sh, flags, tune.refill_min, tune.finish_min, tune.vote_node, tune.vote_tri, (float4 *)rgba, prim, t, counters);
-        else hipLaunchKernelGGL((k_stream<false>), dim3(grid), dim3(RT_BLOCK), 0, st, S, V, sh, flags, tune.refill_min, tune.finish_min, tune.vote_node, tune.vote_tri, (float4 *)rgba, prim, t, counters);
+        if (count) hipLaunchKernelGGL((k_stream<true>), dim3(grid), dim3(RT_BLOCK), 0, st, S, V, sh, flags, tune.refill_min, tune.finish_min, tune.vote_node, tune.vote_tri, tune.uni_min, (float4 *)rgba, prim, t, counters);
+        else hipLaunchKernelGGL((k_stream<false>), dim3(grid), dim3(RT_BLOCK), 0, st, S, V, sh, flags, tune.refill_min, tune.finish_min, tune.vote_node, tune.vote_tri, tune.uni_min, (float4 *)rgba, prim, t, counters);
         return hipGetLastError();
     }
 #define RT_LAUNCH_PRIMARY(C, P) \

@@ -6,8 +6,8 @@ reference-faithful tessellation (ico(5): 7.2 M triangles + ground plane), 1920x1
 ray per pixel + one shadow ray per hit.  A step = one frame through rt_render (C ABI).
 N>1: scene replicated, one process per GPU; --mode frames (default) gives every rank its own
 camera on an orbit (weak scaling, no data-path collective); --mode tiles shards ONE frame by
-64x64 screen tiles round-robin over the ranks and combines with one RCCL all_reduce(sum) of the
-zero-initialised radiance buffers (strong scaling); --mode samples (path-tracing workloads) gives every
+64x64 screen tiles round-robin over the ranks and gathers every rank's packed tiles on rank 0 over RCCL
+(one xGMI link per peer; strong scaling); --mode samples (path-tracing workloads) gives every
 rank its own sample slice of ONE frame and combines the accumulation buffers with one all_reduce(sum)
 (weak scaling in samples: SURVEY 8e, BASELINE.json configs[4]).
 
@@ -186,6 +186,9 @@ def main():
             __cuda_array_interface__ = dict(shape=(H * W * 4,), typestr="<f4", data=(d_rad, False), version=2)
         rad_t = torch.as_tensor(_Ptr(), device=f"cuda:{local_rank}")
         frame_t = torch.empty_like(rad_t)   # combined frame; the library's buffer keeps only this rank's tiles
+        from ray_tracing_amd import multi_gpu
+        gloo = dist.get_backend() == "gloo"
+        gather = multi_gpu.TileGather(W, H, 64, world, rank, 4, "cpu" if gloo else f"cuda:{local_rank}")
 
     acc_t = None
     if samples:
@@ -206,13 +209,15 @@ def main():
                 dist.all_reduce(acc_t, op=dist.ReduceOp.SUM)  # running sums of all ranks' sample slices
             ctx.resolve_accumulation(spp * world)             # radiance = sum / total samples, on the device
         if tiles:
-            frame_t.copy_(rad_t)
-            if dist.get_backend() == "gloo":                  # rehearsal only: gloo reduces host tensors
-                host = frame_t.cpu()
-                dist.all_reduce(host, op=dist.ReduceOp.SUM)
-                frame_t.copy_(host)
+            # every rank sends its own tiles, packed, straight to rank 0: one xGMI link per peer, 1/N of a frame each
+            if gloo:                                          # rehearsal only: gloo moves host tensors
+                host = rad_t.cpu()
+                gather.combine(host)
+                if rank == 0:
+                    frame_t.copy_(host)
             else:
-                dist.all_reduce(frame_t, op=dist.ReduceOp.SUM)   # other ranks' tiles are zero here: sum == gather
+                frame_t.copy_(rad_t)
+                gather.combine(frame_t)
 
     for _ in range(args.warmup):
         step(flags)
@@ -262,7 +267,7 @@ def main():
                        "triangles": int(info.n_triangles), "bvh_nodes": int(info.n_nodes),
                        "rays_per_step_rank0": int(rays_step),
                        "primary_hit_fraction": round(hits / max(cnt.rays_primary, 1), 4), "camera_radii": CAMERA_RADII,
-                       "parallelism": ("tiles64-roundrobin+allreduce" if tiles else
+                       "parallelism": ("tiles64-roundrobin+packed-gather-to-rank0" if tiles else
                                        (f"sample-slices{world}+allreduce" if samples else f"frames-dp{world}"))},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,

@@ -6,6 +6,10 @@
   samples : every rank renders all pixels with its own sample slice (sample_first, stream_id = rank);
             the f32 accumulation buffers are summed with one all_reduce and divided by the total
             sample count (summation order differs from one GPU: RMSE gate, not bits).
+  tiles, gathered : the same tiles, but each rank sends ONLY its own pixels, packed, straight to rank 0
+            (TileGather).  xGMI is point-to-point: a ring all_reduce of the whole frame moves
+            2*(N-1)/N frames over every link (1080p RGBA f32, 8 GPUs: 58 MB per link, ~0.38 ms at 153 GB/s),
+            the direct gather 1/N of a frame over each of the N-1 links into rank 0 (4.1 MB, ~0.03 ms).
 These helpers only move tensors; they work on any torch device.
 """
 import numpy as np
@@ -40,3 +44,28 @@ def wrap_device_buffer(ptr, n_floats, device_index):
     class _Ptr:
         __cuda_array_interface__ = dict(shape=(n_floats,), typestr="<f4", data=(ptr, False), version=2)
     return torch.as_tensor(_Ptr(), device=f"cuda:{device_index}")
+
+
+class TileGather:
+    """Packed-tile gather to rank 0.  Every rank holds a full-frame tensor (H*W*C floats) in which only its own
+    tiles are meaningful; combine() leaves the complete frame in rank 0's tensor.  Index tensors are built once."""
+
+    def __init__(self, width, height, tile, world, rank, channels=4, device="cpu", group=None):
+        import torch
+        self.world, self.rank, self.channels, self.group = world, rank, channels, group
+        owner = tile_owner(width, height, tile, world).reshape(-1)
+        self.idx = [torch.from_numpy(np.flatnonzero(owner == r).astype(np.int64)).to(device) for r in range(world)]
+        self.n_max = max(int(i.numel()) for i in self.idx)          # gather wants equal sizes: pad to the largest share
+        self.send = torch.zeros(self.n_max * channels, dtype=torch.float32, device=device)
+        self.recv = [torch.zeros_like(self.send) for _ in range(world)] if rank == 0 else None
+
+    def combine(self, frame):
+        import torch.distributed as dist
+        px = frame.view(-1, self.channels)
+        mine = self.idx[self.rank]
+        self.send.view(-1, self.channels)[: mine.numel()].copy_(px.index_select(0, mine))
+        dist.gather(self.send, self.recv, dst=0, group=self.group)
+        if self.rank == 0:
+            for r in range(1, self.world):
+                px.index_copy_(0, self.idx[r], self.recv[r].view(-1, self.channels)[: self.idx[r].numel()])
+        return frame

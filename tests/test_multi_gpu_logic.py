@@ -47,6 +47,12 @@ def _worker(rank, world, port, out):
     t = torch.from_numpy(mine.copy())
     multi_gpu.combine_tiles(t)
     tiles_ok = t.numpy().tobytes() == full.tobytes()
+    # the same tiles through the packed gather: rank 0 ends with the full frame, bit for bit
+    g2 = multi_gpu.TileGather(W, H, 16, world, rank)
+    t2 = torch.from_numpy(mine.copy()).reshape(-1)
+    g2.combine(t2)
+    if rank == 0:
+        tiles_ok = tiles_ok and t2.numpy().tobytes() == full.tobytes()
 
     # --- samples: rank r renders samples [2r, 2r+2) with RNG stream id 0 (same stream, disjoint indices)
     acc, _ = orc.render_path(s, v, 2, 4, seed=3, sample_first=2 * rank, threads=1)

@@ -108,6 +108,8 @@ int rt_set_view(rt_ctx *ctx, const float world_from_clip[16], const float world_
 #define RT_FLAG_WAVE_TRAVERSAL 0x0080u /* primary/shadow rays: wave-coherent (packet) BVH traversal, one
                                           node fetch per wave, instead of per-lane traversal; results
                                           are identical (measured slower on the bench scenes) */
+#define RT_FLAG_BINARY_TREE   0x0200u  /* walk the binary tree even when the 4-wide quantised tree was built
+                                          (results are identical; for A/B measurements and tests) */
 
 typedef struct {
     uint32_t struct_size;    /* = sizeof(rt_render_params) */
@@ -183,6 +185,11 @@ int rt_host_bvh_build(const rt_triangle *triangles, size_t n_triangles, const rt
 int rt_host_bvh_refit(rt_host_bvh *bvh, const rt_triangle *triangles, size_t n_triangles,
                       const rt_vertex *vertices, size_t n_vertices, int n_threads);
 int rt_host_bvh_copy(const rt_host_bvh *bvh, void *nodes, size_t node_bytes_total, void *tris, size_t tri_bytes_total);
+/* The 4-wide quantised tree made from the (possibly refitted) binary tree: 64-B nodes and, per node, the four
+ * source slots (16 B).  Call with NULL buffers to get the node count, then with buffers of that many entries.
+ * stack_need: most entries a traversal of it can hold on its stack at once. */
+int rt_host_bvh_wide(const rt_host_bvh *bvh, void *wide_nodes, void *wide_src, size_t capacity_nodes,
+                     size_t *n_wide, uint32_t *stack_need);
 void rt_host_bvh_free(rt_host_bvh *bvh);
 
 const char *rt_last_error(rt_ctx *ctx);   /* ctx may be NULL: last error of rt_create */

@@ -27,6 +27,7 @@ FLAG_ACCUMULATE = 0x0020
 FLAG_TIME_KERNELS = 0x0040
 FLAG_WAVE_TRAVERSAL = 0x0080
 FLAG_STATIC_GRID = 0x0100
+FLAG_BINARY_TREE = 0x0200
 
 MISS_PRIM = 0xFFFFFFFF
 
@@ -42,7 +43,9 @@ assert TRIANGLE.itemsize == 12 and MESH_INFO.itemsize == 48 and VERTEX.itemsize 
 BVH_NODE = np.dtype([("lo0", "<f4", 3), ("hi0", "<f4", 3), ("lo1", "<f4", 3), ("hi1", "<f4", 3),
                      ("child0", "<i4"), ("child1", "<i4"), ("pad", "<u4", 2)])
 TRI_RECORD = np.dtype([("a", "<f4", 3), ("ab", "<f4", 3), ("ac", "<f4", 3), ("tri", "<u4"), ("mesh", "<u4"), ("seq", "<u4")])
-assert BVH_NODE.itemsize == 64 and TRI_RECORD.itemsize == 48
+WIDE_NODE = np.dtype([("org", "<f4", 3), ("scl", "<f4", 3), ("lo", "<u4", 3), ("hi", "<u4", 3), ("child", "<i4", 4)])
+WIDE_SRC = np.dtype([("slot", "<u4", 4)])
+assert BVH_NODE.itemsize == 64 and TRI_RECORD.itemsize == 48 and WIDE_NODE.itemsize == 64 and WIDE_SRC.itemsize == 16
 
 
 class RenderParams(C.Structure):
@@ -76,7 +79,7 @@ class EntityView(C.Structure):
 RT_SYMBOLS = ["rt_create", "rt_destroy", "rt_set_stream", "rt_upload_scene", "rt_upload_scene_ex", "rt_update_vertices", "rt_host_bvh_refit", "rt_set_view", "rt_render",
               "rt_synchronize", "rt_read_radiance", "rt_read_prim_ids", "rt_read_hit_t", "rt_read_bgra8_srgb",
               "rt_read_accumulation", "rt_device_buffers", "rt_resolve_accumulation", "rt_get_counters",
-              "rt_get_bvh_info", "rt_read_bvh", "rt_host_bvh_build", "rt_host_bvh_copy", "rt_host_bvh_free", "rt_last_error", "rt_status_string", "rt_version"]
+              "rt_get_bvh_info", "rt_read_bvh", "rt_host_bvh_build", "rt_host_bvh_copy", "rt_host_bvh_wide", "rt_host_bvh_free", "rt_last_error", "rt_status_string", "rt_version"]
 RTH_SYMBOLS = ["rth_app_create", "rth_app_destroy", "rth_app_finish", "rth_app_update", "rth_app_ctx",
                "rth_last_error", "rth_add_mesh", "rth_add_cuboid", "rth_add_plane", "rth_add_icosphere",
                "rth_add_material", "rth_spawn", "rth_set_transform", "rth_set_aabb", "rth_clear_world",
@@ -115,6 +118,7 @@ def lib():
         "rt_read_bvh": (i, [vp, vp, sz, vp, sz]),
         "rt_host_bvh_build": (i, [vp, sz, vp, sz, vp, sz, i, C.POINTER(vp), C.POINTER(BvhInfo)]),
         "rt_host_bvh_copy": (i, [vp, vp, sz, vp, sz]), "rt_host_bvh_free": (None, [vp]),
+        "rt_host_bvh_wide": (i, [vp, vp, vp, sz, C.POINTER(sz), C.POINTER(C.c_uint32)]),
         "rt_last_error": (C.c_char_p, [vp]), "rt_status_string": (C.c_char_p, [i]), "rt_version": (C.c_char_p, []),
         "rth_app_create": (vp, []), "rth_app_destroy": (None, [vp]), "rth_app_finish": (i, [vp, i]),
         "rth_app_update": (i, [vp, C.POINTER(RenderParams)]), "rth_app_ctx": (vp, [vp]),
@@ -205,9 +209,10 @@ def analytic_sphere_field(n, seed):
     return Scene(ground.triangles, ground.meshes, ground.vertices, mats, spheres, idx)
 
 
-def host_bvh_build(scene, threads=0, refit_to=None):
+def host_bvh_build(scene, threads=0, refit_to=None, wide=False):
     """BVH built on the host only (no GPU): returns (info, nodes, tri_records).
-    refit_to: a Scene with the same topology and moved vertices; the tree is refitted to it before the copy."""
+    refit_to: a Scene with the same topology and moved vertices; the tree is refitted to it before the copy.
+    wide: also return the 4-wide quantised tree made from it: (info, nodes, recs, wide_nodes, wide_src, stack_need)."""
     h, info = C.c_void_p(), BvhInfo()
     t, m, v = scene.triangles, scene.meshes, scene.vertices
     rc = lib().rt_host_bvh_build(t.ctypes.data, t.size, m.ctypes.data, m.size, v.ctypes.data, v.size, threads,
@@ -222,6 +227,15 @@ def host_bvh_build(scene, threads=0, refit_to=None):
             raise RtError(rc, "rt_host_bvh_refit")
     nodes, recs = np.empty(info.n_nodes, dtype=BVH_NODE), np.empty(info.n_triangles, dtype=TRI_RECORD)
     lib().rt_host_bvh_copy(h, nodes.ctypes.data, nodes.nbytes, recs.ctypes.data, recs.nbytes)
+    if wide:
+        n, need = C.c_size_t(), C.c_uint32()
+        lib().rt_host_bvh_wide(h, None, None, 0, C.byref(n), C.byref(need))
+        wn, ws = np.zeros(n.value, dtype=WIDE_NODE), np.zeros(n.value, dtype=WIDE_SRC)
+        rc = lib().rt_host_bvh_wide(h, wn.ctypes.data, ws.ctypes.data, n.value, C.byref(n), C.byref(need))
+        lib().rt_host_bvh_free(h)
+        if rc != RT_OK:
+            raise RtError(rc, "rt_host_bvh_wide")
+        return info, nodes, recs, wn, ws, need.value
     lib().rt_host_bvh_free(h)
     return info, nodes, recs
 

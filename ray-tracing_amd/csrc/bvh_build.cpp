@@ -1,6 +1,7 @@
 // bvh_build.cpp -- binned-SAH BVH2 builder over the reference's (mesh, triangle) loop items.
 // Build-side design (reference src/bvh.rs:1 is empty).  Host code, no GPU calls.
 #include "bvh_build.h"
+#include "rt_wide.h"
 
 #include <algorithm>
 #include <atomic>
@@ -388,4 +389,80 @@ bool rt_bvh_refit(RtBvhBuildResult *bvh, const rt_triangle *tris, const rt_verte
     }
     bvh->build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return true;
+}
+
+void rt_bvh_widen(const RtBvhBuildResult &bvh, RtWideTree *out) {
+    auto t0 = std::chrono::steady_clock::now();
+    out->nodes.clear(); out->src.clear(); out->max_depth = 0; out->stack_need = 0;
+    if (bvh.nodes.empty()) { out->build_ms = 0.0; return; }
+    struct Slot { int32_t code; uint32_t src; float area; };
+    struct Item { uint32_t bin, wide, depth; };
+    auto slots_of = [&](uint32_t n, Slot *s) {
+        const RtBvhNode &N = bvh.nodes[n];
+        int c = 0;
+        if (N.child0 != RT_CHILD_NONE) s[c++] = {N.child0, (n << 1) | 0u, half_area(N.lo0, N.hi0)};
+        if (N.child1 != RT_CHILD_NONE) s[c++] = {N.child1, (n << 1) | 1u, half_area(N.lo1, N.hi1)};
+        return c;
+    };
+    out->nodes.reserve(bvh.nodes.size() / 2 + 1);
+    out->src.reserve(bvh.nodes.size() / 2 + 1);
+    std::vector<Item> stack;
+    out->nodes.emplace_back(); out->src.emplace_back();
+    stack.push_back({0u, 0u, 0u});
+    while (!stack.empty()) {
+        Item it = stack.back(); stack.pop_back();
+        out->max_depth = std::max(out->max_depth, it.depth);
+        Slot s[4];
+        int n = slots_of(it.bin, s);
+        while (n < 4) {
+            int best = -1;
+            for (int k = 0; k < n; ++k)
+                if (s[k].code >= 0 && (best < 0 || s[k].area > s[best].area)) best = k;
+            if (best < 0) break;
+            Slot two[2];
+            int m = slots_of((uint32_t)s[best].code, two);
+            if (n - 1 + m > 4) break;
+            // the two children take the place of their parent, order kept
+            for (int k = n - 1; k > best; --k) s[k + m - 1] = s[k];
+            for (int k = 0; k < m; ++k) s[best + k] = two[k];
+            n += m - 1;
+            if (m == 0) break;   // cannot happen (an inner node has at least one child); guards the loop
+        }
+        RtWideNode W;
+        RtWideSrc S;
+        std::memset(&W, 0, sizeof W);
+        for (int k = 0; k < 4; ++k) {
+            if (k >= n) { W.child[k] = RT_CHILD_NONE; S.slot[k] = RT_WIDE_EMPTY; continue; }
+            S.slot[k] = s[k].src;
+            if (s[k].code >= 0) {
+                uint32_t idx = (uint32_t)out->nodes.size();
+                out->nodes.emplace_back(); out->src.emplace_back();
+                W.child[k] = (int32_t)idx;
+                stack.push_back({(uint32_t)s[k].code, idx, it.depth + 1});
+            } else W.child[k] = s[k].code;
+        }
+        rt_wide_quantise(bvh.nodes.data(), S, W);
+        out->nodes[it.wide] = W; out->src[it.wide] = S;
+    }
+    // worst-case stack use: with n children hit, n-1 wait on the stack while the first subtree is walked, n-2
+    // during the second, ...; the worst order visits the neediest subtree first
+    std::vector<uint32_t> need(out->nodes.size(), 0);
+    for (size_t i = out->nodes.size(); i-- > 0;) {
+        uint32_t sub[4]; int n = 0;
+        for (int k = 0; k < 4; ++k) {
+            int32_t c = out->nodes[i].child[k];
+            if (c == RT_CHILD_NONE) continue;
+            sub[n++] = c >= 0 ? need[c] : 0u;
+        }
+        std::sort(sub, sub + n, [](uint32_t a, uint32_t b) { return a > b; });
+        uint32_t w = 0;
+        for (int k = 0; k < n; ++k) w = std::max(w, sub[k] + (uint32_t)(n - 1 - k));
+        need[i] = w;
+    }
+    out->stack_need = need[0];
+    out->build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+}
+
+void rt_wide_requantise(const RtBvhBuildResult &bvh, RtWideTree *w) {
+    for (size_t i = 0; i < w->nodes.size(); ++i) rt_wide_quantise(bvh.nodes.data(), w->src[i], w->nodes[i]);
 }

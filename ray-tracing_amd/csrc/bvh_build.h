@@ -27,3 +27,17 @@ void rt_bvh_build(const rt_triangle *tris, size_t n_tris, const rt_mesh_info *me
 // that triangle): the caller then rebuilds.
 bool rt_bvh_refit(RtBvhBuildResult *bvh, const rt_triangle *tris, const rt_vertex *verts, int n_threads,
                   const rt_sphere *spheres = nullptr, size_t n_tris = 0);
+
+// 4-wide quantised tree over the same records (rt_layout.h RtWideNode): the binary tree collapsed greedily --
+// starting from a node's two children, the inner child with the largest box is replaced by its own two children
+// until four slots are used -- and the child boxes quantised (rt_wide.h).  src keeps, per slot, which binary-tree
+// box it was made from, so that a refit of the binary tree is followed by a plain re-quantisation.
+struct RtWideTree {
+    std::vector<RtWideNode> nodes;    // nodes[0] is the root; children are stored after their parent
+    std::vector<RtWideSrc> src;
+    uint32_t max_depth = 0;
+    uint32_t stack_need = 0;          // most entries a traversal can have on its stack at once
+    double build_ms = 0.0;
+};
+void rt_bvh_widen(const RtBvhBuildResult &bvh, RtWideTree *out);
+void rt_wide_requantise(const RtBvhBuildResult &bvh, RtWideTree *w);   // after rt_bvh_refit

@@ -34,7 +34,7 @@ struct rt_ctx {
     bool has_scene = false;
     RtSceneDev S{};
     void *d_nodes = nullptr, *d_recs = nullptr, *d_tris = nullptr, *d_meshes = nullptr, *d_verts = nullptr,
-         *d_mats = nullptr, *d_spheres = nullptr, *d_sphere_mats = nullptr;
+         *d_mats = nullptr, *d_spheres = nullptr, *d_sphere_mats = nullptr, *d_wide = nullptr, *d_wide_src = nullptr;
     rt_bvh_info info{};
     RtBvhBuildResult bvh_host;            // host copy of the tree (RT_TUNE_HOST_REFIT path)
     bool bvh_host_stale = false;          // the device tree has been refitted since
@@ -65,6 +65,8 @@ struct rt_ctx {
     uint64_t primary_total = 0;
 
     RtTune tune{};
+    uint32_t tune_wide = 0;               // build and walk the 4-wide quantised tree
+    RtWideTree wide_host;
 
     // kernel timing
     std::vector<hipEvent_t> ev;            // pairs: start, stop
@@ -93,6 +95,7 @@ void free_scene(rt_ctx *c) {
     free_dev(c->d_nodes); free_dev(c->d_recs); free_dev(c->d_tris);
     free_dev(c->d_meshes); free_dev(c->d_verts); free_dev(c->d_mats);
     free_dev(c->d_spheres); free_dev(c->d_sphere_mats); free_dev(c->d_level_nodes);
+    free_dev(c->d_wide); free_dev(c->d_wide_src);
     c->level_count.clear();
     c->has_scene = false;
     std::memset(&c->S, 0, sizeof c->S);
@@ -200,6 +203,9 @@ int rt_create(int device_ordinal, rt_ctx **out) {
         c->tune.vote_node = env("RT_TUNE_VOTE_NODE", 3, 1, 64);
         c->tune.vote_tri = env("RT_TUNE_VOTE_TRI", 1, 1, 64);
         c->tune.uni_min = env("RT_TUNE_UNI_MIN", 16, 1, 65);
+        c->tune.wide_vote_node = env("RT_TUNE_WIDE_VOTE_NODE", 3, 1, 64);
+        c->tune.wide_vote_tri = env("RT_TUNE_WIDE_VOTE_TRI", 1, 1, 64);
+        c->tune_wide = env("RT_TUNE_WIDE", 0, 0, 1);
     }
     int rc = RT_OK;
     do {
@@ -312,6 +318,24 @@ int rt_host_bvh_refit(rt_host_bvh *h, const rt_triangle *tris, size_t n_tris, co
     }
     return rt_bvh_refit(&h->r, tris, verts, n_threads) ? RT_OK : RT_ERR_SCENE;
 }
+int rt_host_bvh_wide(const rt_host_bvh *h, void *wide_nodes, void *wide_src, size_t capacity_nodes, size_t *n_wide,
+                     uint32_t *stack_need) {
+    if (!h || !n_wide) return RT_ERR_ARG;
+    RtWideTree w;
+    try {
+        rt_bvh_widen(h->r, &w);
+    } catch (const std::bad_alloc &) {
+        return fail(nullptr, RT_ERR_OOM, "rt_host_bvh_wide: host allocation failed");
+    }
+    *n_wide = w.nodes.size();
+    if (stack_need) *stack_need = w.stack_need;
+    if (wide_nodes || wide_src) {
+        if (capacity_nodes < w.nodes.size()) return RT_ERR_ARG;
+        if (wide_nodes && !w.nodes.empty()) std::memcpy(wide_nodes, w.nodes.data(), w.nodes.size() * sizeof(RtWideNode));
+        if (wide_src && !w.src.empty()) std::memcpy(wide_src, w.src.data(), w.src.size() * sizeof(RtWideSrc));
+    }
+    return RT_OK;
+}
 void rt_host_bvh_free(rt_host_bvh *h) { delete h; }
 
 int rt_upload_scene(rt_ctx *c, const rt_triangle *tris, size_t n_tris, const rt_mesh_info *meshes, size_t n_meshes,
@@ -377,8 +401,24 @@ int rt_upload_scene_ex(rt_ctx *c, const rt_triangle *tris, size_t n_tris, const 
         if ((rc = upload(c, c->d_level_nodes, order.data(), nn)) != RT_OK) return rc;
         c->level_count = count;
     }
+    c->wide_host = RtWideTree();
+    if (c->tune_wide && !bvh.nodes.empty()) {
+        try {
+            rt_bvh_widen(bvh, &c->wide_host);
+        } catch (const std::bad_alloc &) {
+            return fail(c, RT_ERR_OOM, "rt_upload_scene: host allocation failed in the wide-tree build");
+        }
+        // a tree whose worst-case walk does not fit the per-lane stack keeps the binary tree (RT_MAX_DEPTH bounds that one)
+        if (c->wide_host.stack_need + 1 > RT_STACK_CAP) c->wide_host = RtWideTree();
+        else {
+            if ((rc = upload(c, c->d_wide, c->wide_host.nodes.data(), c->wide_host.nodes.size())) != RT_OK) return rc;
+            if ((rc = upload(c, c->d_wide_src, c->wide_host.src.data(), c->wide_host.src.size())) != RT_OK) return rc;
+        }
+    }
     HIPCHK(c, hipStreamSynchronize(c->stream));   // host arrays are borrowed for this call only
 
+    c->S.wide = (const RtWideNode *)c->d_wide;
+    c->S.n_wide = (uint32_t)c->wide_host.nodes.size();
     c->S.nodes = (const RtBvhNode *)c->d_nodes;
     c->S.recs = (const RtTriRecord *)c->d_recs;
     c->S.tris = (const rt_triangle *)c->d_tris;
@@ -462,6 +502,7 @@ int rt_update_vertices(rt_ctx *c, const rt_vertex *verts, size_t n_verts, const 
         refit_ms = ms;
         c->bvh_host_stale = true;
     }
+    c->S.n_wide = 0;                              // TODO(wide): re-quantise after the refit
     c->h_meshes.assign(meshes, meshes + n_meshes);
     c->info.build_ms = refit_ms;
     c->info.n_refits += 1;

@@ -17,7 +17,9 @@
 #ifndef RT_MIN_WAVES
 #define RT_MIN_WAVES 8
 #endif
-#define RT_STACK_OVF (RT_MAX_DEPTH + 2 - RT_STACK_LDS)
+// private part: a binary tree needs <= RT_MAX_DEPTH entries in all, a 4-wide tree up to 3 per level (the host
+// checks RtWideTree::stack_need against RT_STACK_CAP before it enables the wide tree)
+#define RT_STACK_OVF (RT_STACK_CAP - RT_STACK_LDS)
 #define RT_INF __builtin_huge_valf()
 
 struct f3 { float x, y, z; };
@@ -574,7 +576,65 @@ __device__ __forceinline__ void node_decide(Q q0, Q q1, Q q2, Q q3, f3 o, f3 inv
     else cur = stack_pop(sp, stk, ovf);
 }
 
-template <bool COUNT>
+// One step on the 4-wide tree: four quantised child boxes against the lane's ray, the hit ones sorted by entry
+// distance, nearest taken, the others pushed farthest first.  Plane = org + byte*scl, so with A = scl*inv and
+// B = (o - org)*inv the slab distance is ONE fma per plane: byte*A - B (NaN / inf from a zero direction component
+// are dropped by min/max, i.e. the axis does not constrain -- conservative).  The boxes contain the binary tree's
+// (rt_wide.h), the far distance gets 8 ulp of relative slack for the rounding of this form with a distant origin.
+// The wide step's  byte*A - B  form cannot use an infinite 1/d (inf - inf): a direction component of (nearly) zero
+// gets +-1e30 instead -- the ray then drifts 1e-30 per unit of t on that axis, far inside the 1e-12 every box is
+// padded with (rt_wide.h).  The per-mesh cull of wgsl:155 still takes the exact 1/d.
+#define RT_WIDE_INV_MAX 1e30f
+template <bool WIDE>
+__device__ __forceinline__ f3 ray_inv(f3 d) {
+    f3 inv = F3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    if (WIDE) inv = F3(fminf(fmaxf(inv.x, -RT_WIDE_INV_MAX), RT_WIDE_INV_MAX), fminf(fmaxf(inv.y, -RT_WIDE_INV_MAX), RT_WIDE_INV_MAX),
+                       fminf(fmaxf(inv.z, -RT_WIDE_INV_MAX), RT_WIDE_INV_MAX));
+    return inv;
+}
+__device__ __forceinline__ float ub(uint32_t w, int k) { return (float)((w >> (8 * k)) & 0xFFu); }   // v_cvt_f32_ubyteK
+template <class Q>
+__device__ __forceinline__ void wide_decide(Q q0, Q q1, Q q2, Q q3, f3 o, f3 inv, float t, int &cur, int &sp, lds_int *stk,
+                                            prv_int *ovf) {
+    const float limit = t * 1.00001f;   // relaxed bound: near-ties are still visited, seq decides
+    const float Ax = q0.w * inv.x, Ay = q1.x * inv.y, Az = q1.y * inv.z;
+    const float Bx = (o.x - q0.x) * inv.x, By = (o.y - q0.y) * inv.y, Bz = (o.z - q0.z) * inv.z;
+    const uint32_t lox = __float_as_uint(q1.z), loy = __float_as_uint(q1.w), loz = __float_as_uint(q2.x);
+    const uint32_t hix = __float_as_uint(q2.y), hiy = __float_as_uint(q2.z), hiz = __float_as_uint(q2.w);
+    const bool sx = inv.x < 0.0f, sy = inv.y < 0.0f, sz = inv.z < 0.0f;
+    const uint32_t nx = sx ? hix : lox, fx = sx ? lox : hix;
+    const uint32_t ny = sy ? hiy : loy, fy = sy ? loy : hiy;
+    const uint32_t nz = sz ? hiz : loz, fz = sz ? loz : hiz;
+    uint32_t key[4]; int ref[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        float tn = fmaxf(fmaxf(__builtin_fmaf(ub(nx, k), Ax, -Bx), __builtin_fmaf(ub(ny, k), Ay, -By)), __builtin_fmaf(ub(nz, k), Az, -Bz));
+        float tf = fminf(fminf(__builtin_fmaf(ub(fx, k), Ax, -Bx), __builtin_fmaf(ub(fy, k), Ay, -By)), __builtin_fmaf(ub(fz, k), Az, -Bz));
+        tn = fmaxf(tn, 0.0f);
+        tf = fminf(tf * 1.000001f, limit);
+        const int c = __float_as_int(k == 0 ? q3.x : (k == 1 ? q3.y : (k == 2 ? q3.z : q3.w)));
+        const bool hit = tn <= tf && c != RT_CHILD_NONE;
+        key[k] = hit ? __float_as_uint(tn) : 0xFFFFFFFFu;      // tn >= 0: its bits order like the value
+        ref[k] = hit ? c : RT_CHILD_NONE;
+    }
+#define RT_CE(a, b) { const bool s_ = key[b] < key[a]; const uint32_t ka = s_ ? key[b] : key[a], kb = s_ ? key[a] : key[b]; \
+                      const int ra = s_ ? ref[b] : ref[a], rb = s_ ? ref[a] : ref[b]; key[a] = ka; key[b] = kb; ref[a] = ra; ref[b] = rb; }
+    RT_CE(0, 1) RT_CE(2, 3) RT_CE(0, 2) RT_CE(1, 3) RT_CE(1, 2)
+#undef RT_CE
+    if (sp + 3 <= RT_STACK_LDS) {      // the usual case: three slots left in the LDS part
+        if (ref[3] != RT_CHILD_NONE) { stk[sp * RT_BLOCK] = ref[3]; ++sp; }
+        if (ref[2] != RT_CHILD_NONE) { stk[sp * RT_BLOCK] = ref[2]; ++sp; }
+        if (ref[1] != RT_CHILD_NONE) { stk[sp * RT_BLOCK] = ref[1]; ++sp; }
+    } else {
+        if (ref[3] != RT_CHILD_NONE) stack_push(sp, stk, ovf, ref[3]);
+        if (ref[2] != RT_CHILD_NONE) stack_push(sp, stk, ovf, ref[2]);
+        if (ref[1] != RT_CHILD_NONE) stack_push(sp, stk, ovf, ref[1]);
+    }
+    if (ref[0] != RT_CHILD_NONE) cur = ref[0];
+    else cur = stack_pop(sp, stk, ovf);
+}
+
+template <bool COUNT, bool WIDE>
 __global__ __launch_bounds__(RT_BLOCK, RT_MIN_WAVES) void k_stream(
     RtSceneDev S_, RtViewDev V_, RtShardDev sh_, uint32_t flags, uint32_t refill_min, uint32_t finish_min,
     uint32_t vote_node, uint32_t vote_tri, uint32_t uni_min, float4 *__restrict__ rgba, uint32_t *__restrict__ prim,
@@ -589,7 +649,8 @@ __global__ __launch_bounds__(RT_BLOCK, RT_MIN_WAVES) void k_stream(
     lds_int *stk = (lds_int *)(s_stack + threadIdx.x);
     int ovf_mem[RT_STACK_OVF];
     prv_int *ovf = (prv_int *)ovf_mem;
-    const RtBvhNode *const nodes = S_.nodes;
+    // the wide tree's nodes are 64 B as well: the fetch code is shared, only the decision differs
+    const RtBvhNode *const nodes = WIDE ? reinterpret_cast<const RtBvhNode *>(S_.wide) : S_.nodes;
     const RtTriRecord *const recs = S_.recs;
     const rt_mesh_info *const meshes = S_.meshes;
     const uint32_t lane = threadIdx.x & 63u;
@@ -608,6 +669,9 @@ __global__ __launch_bounds__(RT_BLOCK, RT_MIN_WAVES) void k_stream(
     int cur = RT_DONE, sp = 0;
     int state = 0;                 // 0 idle, 1 primary ray, 2 shadow ray
     uint32_t idx = 0;
+#ifdef RT_TRIP_LIMIT
+    uint32_t dbg_trips = 0;
+#endif
     for (;;) {
         // ================= service: runs when the hot loop below asks for it =================================
         // ---- 1. finish ended rays (shade, write, start the shadow ray) -----------------------------------------
@@ -626,7 +690,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_MIN_WAVES) void k_stream(
                 out_prim = h.tri; out_t = t;
                 if (flags & RT_FLAG_SHADOW) {
                     o = add(point, scl(normal, 1e-3f)); d = F3(0.0f, 1.0f, 0.0f);
-                    inv = F3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+                    inv = ray_inv<WIDE>(d);
                     t = RT_INF; seq = 0xFFFFFFFFu; rec = 0xFFFFFFFFu;
                     cur = 0; sp = 0;
                     state = 2;
@@ -679,7 +743,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_MIN_WAVES) void k_stream(
                     uint32_t px, py;
                     if (w < RT_REGION_PX && pixel_of_region(V, sh, reg_q, reg_r, w, px, py)) {
                         ray_gen(V, px, py, o, d);
-                        inv = F3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+                        inv = ray_inv<WIDE>(d);
                         t = RT_INF; seq = 0xFFFFFFFFu; rec = 0xFFFFFFFFu;
                         cur = S.n_nodes ? 0 : RT_DONE; sp = 0;
                         idx = py * V.width + px;
@@ -717,13 +781,30 @@ __global__ __launch_bounds__(RT_BLOCK, RT_MIN_WAVES) void k_stream(
                     q4 q2 = {sp_[8], sp_[9], sp_[10], sp_[11]}, q3 = {sp_[12], sp_[13], sp_[14], sp_[15]};
                     if (cur >= 0) {
                         if (COUNT) { c.nodes++; if (lane == (uint32_t)__builtin_ctzll(m_node)) { c.wnodes++; c.walive += n_node + n_leaf; } }
-                        node_decide(q0, q1, q2, q3, o, inv, t, cur, sp, stk, ovf);
+#ifdef RT_TRIP_LIMIT
+                        const int cur_was = cur;
+#endif
+                        if (WIDE) wide_decide(q0, q1, q2, q3, o, inv, t, cur, sp, stk, ovf);
+                        else node_decide(q0, q1, q2, q3, o, inv, t, cur, sp, stk, ovf);
+#ifdef RT_TRIP_LIMIT
+                        if (idx == RT_DBG_PIXEL && state == 1) printf("S node %d -> %d sp %d t %g\n", cur_was, cur, sp, t);
+#endif
                     }
                 } else if (cur >= 0) {
                     const float4 *p = reinterpret_cast<const float4 *>(nodes + cur);
                     float4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3];
                     if (COUNT) { c.nodes++; if (lane == (uint32_t)__builtin_ctzll(m_node)) { c.wnodes++; c.walive += n_node + n_leaf; } }
-                    node_decide(q0, q1, q2, q3, o, inv, t, cur, sp, stk, ovf);
+#ifdef RT_TRIP_LIMIT
+                    const int cur_was = cur;
+#endif
+                    if (WIDE) wide_decide(q0, q1, q2, q3, o, inv, t, cur, sp, stk, ovf);
+                    else node_decide(q0, q1, q2, q3, o, inv, t, cur, sp, stk, ovf);
+#ifdef RT_TRIP_LIMIT
+                    if (idx == RT_DBG_PIXEL && state == 1)
+                        printf("V node %d -> %d sp %d t %g | org %g %g %g scl %g %g %g lo %08x %08x %08x hi %08x %08x %08x ch %d %d %d %d | o %g %g %g inv %g %g %g\n", cur_was, cur, sp, t,
+                               q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, __float_as_uint(q1.z), __float_as_uint(q1.w), __float_as_uint(q2.x), __float_as_uint(q2.y), __float_as_uint(q2.z), __float_as_uint(q2.w),
+                               __float_as_int(q3.x), __float_as_int(q3.y), __float_as_int(q3.z), __float_as_int(q3.w), o.x, o.y, o.z, inv.x, inv.y, inv.z);
+#endif
                 }
             } else {
                 if (cur < 0 && cur != RT_DONE) {
@@ -741,7 +822,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_MIN_WAVES) void k_stream(
                         if (ok && !(flags & RT_FLAG_NO_MESH_CULL) && __float_as_uint(r2.z) != RT_REC_SPHERE) {   // per-mesh AABB cull of wgsl:155
                             const float4 *mp = reinterpret_cast<const float4 *>(meshes + __float_as_uint(r2.z));
                             float4 m1 = mp[1], m2 = mp[2];
-                            ok = ray_aabb_ref(o, inv, F3(m1.x, m1.y, m1.z), F3(m2.x, m2.y, m2.z));
+                            ok = ray_aabb_ref(o, WIDE ? ray_inv<false>(d) : inv, F3(m1.x, m1.y, m1.z), F3(m2.x, m2.y, m2.z));
                             if (COUNT) c.meshes++;
                         }
                         if (ok) { t = dst; seq = sq; rec = first; hu = u; hv = v; }
@@ -754,6 +835,16 @@ __global__ __launch_bounds__(RT_BLOCK, RT_MIN_WAVES) void k_stream(
             n_done = (uint32_t)__builtin_popcountll(__ballot(cur == RT_DONE));
             n_pend = n_done - n_idle;
             n_live = 64u - n_done;
+#ifdef RT_TRIP_LIMIT      // debug builds only: a wave that loops too long reports a live lane's state and leaves
+            if (++dbg_trips > RT_TRIP_LIMIT) {
+                const unsigned long long live = __ballot(cur != RT_DONE);
+                if (live && lane == (uint32_t)__builtin_ctzll(live)) {
+                    counters[RT_CNT_BOUNCE] = ((unsigned long long)(uint32_t)cur << 32) | (uint32_t)sp;
+                    counters[RT_CNT_MESH] = ((unsigned long long)__float_as_uint(t) << 32) | idx;
+                }
+                return;
+            }
+#endif
         } while (!(n_live == 0u || n_pend >= finish_min || (more && n_done >= refill_min)));
     }
     wave_sum(counters + RT_CNT_PRIMARY, n_primary);
@@ -1100,14 +1191,19 @@ hipError_t rtk_launch_primary(hipStream_t st, const RtSceneDev &S, const RtViewD
         // at 1080p: 0.27 ms with 3 blocks per CU, 0.37 with 8; tools/occupancy_sweep.py).
         uint32_t per_cu = tune.blocks_per_cu;
         if (per_cu == 0) {
-            size_t tree = (size_t)S.n_nodes * sizeof(RtBvhNode) + (size_t)S.n_recs * sizeof(RtTriRecord);
+            const bool w_ = S.n_wide != 0u && !(flags & RT_FLAG_BINARY_TREE);
+            size_t tree = (size_t)(w_ ? S.n_wide : S.n_nodes) * sizeof(RtBvhNode) + (size_t)S.n_recs * sizeof(RtTriRecord);
             per_cu = tree <= ((size_t)4 << 20) ? 3u : (tree <= ((size_t)16 << 20) ? 5u : 8u);
         }
         uint32_t need = (sh.n_owned * sh.tile * sh.tile + RT_BLOCK - 1) / RT_BLOCK;
         uint32_t grid = tune.cus * per_cu < need ? tune.cus * per_cu : need;
         if (grid == 0) return hipSuccess;
-        if (count) hipLaunchKernelGGL((k_stream<true>), dim3(grid), dim3(RT_BLOCK), 0, st, S, V, sh, flags, tune.refill_min, tune.finish_min, tune.vote_node, tune.vote_tri, tune.uni_min, (float4 *)rgba, prim, t, counters);
-        else hipLaunchKernelGGL((k_stream<false>), dim3(grid), dim3(RT_BLOCK), 0, st, S, V, sh, flags, tune.refill_min, tune.finish_min, tune.vote_node, tune.vote_tri, tune.uni_min, (float4 *)rgba, prim, t, counters);
+        const bool wide = S.n_wide != 0u && !(flags & RT_FLAG_BINARY_TREE);
+#define RT_LAUNCH_STREAM(C, W, VN, VT) \
+    hipLaunchKernelGGL((k_stream<C, W>), dim3(grid), dim3(RT_BLOCK), 0, st, S, V, sh, flags, tune.refill_min, tune.finish_min, VN, VT, tune.uni_min, (float4 *)rgba, prim, t, counters)
+        if (wide) { if (count) RT_LAUNCH_STREAM(true, true, tune.wide_vote_node, tune.wide_vote_tri); else RT_LAUNCH_STREAM(false, true, tune.wide_vote_node, tune.wide_vote_tri); }
+        else { if (count) RT_LAUNCH_STREAM(true, false, tune.vote_node, tune.vote_tri); else RT_LAUNCH_STREAM(false, false, tune.vote_node, tune.vote_tri); }
+#undef RT_LAUNCH_STREAM
         return hipGetLastError();
     }
 #define RT_LAUNCH_PRIMARY(C, P) \

@@ -22,6 +22,25 @@ static_assert(sizeof(RtBvhNode) == 64, "node must be 64 B");
 #define RT_CHILD_NONE ((int32_t)0x80000000)
 #define RT_MAX_LEAF 4
 #define RT_MAX_DEPTH 48   // builder guarantee; the kernels size their stacks from it
+#define RT_STACK_CAP 80   // entries of the per-lane traversal stack (LDS part + private part)
+
+// Wide node: up to FOUR children, their boxes as 8-bit offsets on a per-node grid -- 64 B as well, so one fetch
+// decides four descents and the dependent fetches per ray roughly halve.  Plane of child k on axis a:
+//   org[a] + byte_k(lo_a or hi_a) * scl[a]          (byte k of the packed word = child k)
+// The grid boxes CONTAIN the binary tree's boxes they were made from (rt_wide.h: expanded by 2e-6 of the
+// coordinate magnitude, then floor / ceil), so culling stays conservative and results do not change.
+// child[k] uses the binary tree's codes: >= 0 index of a WIDE node, < 0 leaf code, RT_CHILD_NONE = empty slot.
+//   q0 = org.xyz, scl.x    q1 = scl.yz, lo_x, lo_y    q2 = lo_z, hi_x, hi_y, hi_z    q3 = child[0..3]
+struct alignas(16) RtWideNode {
+    float org[3]; float sclx;
+    float scly, sclz; uint32_t lox, loy;
+    uint32_t loz, hix, hiy, hiz;
+    int32_t child[4];
+};
+static_assert(sizeof(RtWideNode) == 64, "wide node must be 64 B");
+// Where the four boxes of a wide node come from: (binary node index << 1) | child side; RT_WIDE_EMPTY = none.
+struct RtWideSrc { uint32_t slot[4]; };
+#define RT_WIDE_EMPTY 0xFFFFFFFFu
 
 // One leaf triangle record = 48 B, stored in BVH leaf order so a leaf is one contiguous run.
 // a, ab = b-a, ac = c-a are the exact f32 values ray_triangle computes first
@@ -55,7 +74,8 @@ struct RtSceneDev {
     const rt_material *mats;
     const rt_sphere *spheres;          // extension: analytic spheres and their material indices
     const uint32_t *sphere_mats;
-    uint32_t n_nodes, n_recs, n_tris, n_meshes, n_verts, n_mats, n_spheres, pad_;
+    const RtWideNode *wide;            // 4-wide quantised tree over the same records (n_wide = 0: not built)
+    uint32_t n_nodes, n_recs, n_tris, n_meshes, n_verts, n_mats, n_spheres, n_wide;
 };
 
 struct RtViewDev {

@@ -172,10 +172,14 @@ typedef struct {
     double   build_ms;               /* of the last build or refit */
     double   sah_cost;               /* of the last full build */
     uint32_t n_builds, n_refits;     /* since rt_create */
+    uint64_t n_wide_nodes;           /* 4-wide quantised tree over the same records (0: not built); 64 B per node */
+    uint32_t wide_max_depth, wide_stack_need;
 } rt_bvh_info;
 int rt_get_bvh_info(rt_ctx *ctx, rt_bvh_info *out);
 /* Copy the flattened BVH out (host buffers sized from rt_get_bvh_info). */
 int rt_read_bvh(rt_ctx *ctx, void *nodes, size_t node_bytes_total, void *tris, size_t tri_bytes_total);
+/* Copy the 4-wide tree out: n_wide_nodes * 64 bytes (node layout: ray-tracing_amd/csrc/rt_layout.h RtWideNode). */
+int rt_read_bvh_wide(rt_ctx *ctx, void *wide_nodes, size_t bytes_total);
 
 /* Host-only BVH build over the same arrays (no GPU touched): lets the builder and the flattened
  * layout be checked on a machine without a device.  Sizes from *info, then copy, then free. */

@@ -65,7 +65,8 @@ class BvhInfo(C.Structure):
     _fields_ = [("n_nodes", C.c_uint64), ("n_triangles", C.c_uint64), ("n_meshes", C.c_uint64),
                 ("n_vertices", C.c_uint64), ("node_bytes", C.c_uint32), ("tri_bytes", C.c_uint32),
                 ("max_depth", C.c_uint32), ("max_leaf", C.c_uint32), ("build_ms", C.c_double),
-                ("sah_cost", C.c_double), ("n_builds", C.c_uint32), ("n_refits", C.c_uint32)]
+                ("sah_cost", C.c_double), ("n_builds", C.c_uint32), ("n_refits", C.c_uint32),
+                ("n_wide_nodes", C.c_uint64), ("wide_max_depth", C.c_uint32), ("wide_stack_need", C.c_uint32)]
 
 
 class EntityView(C.Structure):
@@ -79,7 +80,7 @@ class EntityView(C.Structure):
 RT_SYMBOLS = ["rt_create", "rt_destroy", "rt_set_stream", "rt_upload_scene", "rt_upload_scene_ex", "rt_update_vertices", "rt_host_bvh_refit", "rt_set_view", "rt_render",
               "rt_synchronize", "rt_read_radiance", "rt_read_prim_ids", "rt_read_hit_t", "rt_read_bgra8_srgb",
               "rt_read_accumulation", "rt_device_buffers", "rt_resolve_accumulation", "rt_get_counters",
-              "rt_get_bvh_info", "rt_read_bvh", "rt_host_bvh_build", "rt_host_bvh_copy", "rt_host_bvh_wide", "rt_host_bvh_free", "rt_last_error", "rt_status_string", "rt_version"]
+              "rt_get_bvh_info", "rt_read_bvh", "rt_read_bvh_wide", "rt_host_bvh_build", "rt_host_bvh_copy", "rt_host_bvh_wide", "rt_host_bvh_free", "rt_last_error", "rt_status_string", "rt_version"]
 RTH_SYMBOLS = ["rth_app_create", "rth_app_destroy", "rth_app_finish", "rth_app_update", "rth_app_ctx",
                "rth_last_error", "rth_add_mesh", "rth_add_cuboid", "rth_add_plane", "rth_add_icosphere",
                "rth_add_material", "rth_spawn", "rth_set_transform", "rth_set_aabb", "rth_clear_world",
@@ -118,6 +119,7 @@ def lib():
         "rt_read_bvh": (i, [vp, vp, sz, vp, sz]),
         "rt_host_bvh_build": (i, [vp, sz, vp, sz, vp, sz, i, C.POINTER(vp), C.POINTER(BvhInfo)]),
         "rt_host_bvh_copy": (i, [vp, vp, sz, vp, sz]), "rt_host_bvh_free": (None, [vp]),
+        "rt_read_bvh_wide": (i, [vp, vp, sz]),
         "rt_host_bvh_wide": (i, [vp, vp, vp, sz, C.POINTER(sz), C.POINTER(C.c_uint32)]),
         "rt_last_error": (C.c_char_p, [vp]), "rt_status_string": (C.c_char_p, [i]), "rt_version": (C.c_char_p, []),
         "rth_app_create": (vp, []), "rth_app_destroy": (None, [vp]), "rth_app_finish": (i, [vp, i]),
@@ -348,6 +350,11 @@ class Context:
         recs = np.empty(b.n_triangles, dtype=TRI_RECORD)
         self._chk(lib().rt_read_bvh(self._h, nodes.ctypes.data, nodes.nbytes, recs.ctypes.data, recs.nbytes))
         return nodes, recs
+
+    def read_bvh_wide(self):
+        wide = np.empty(self.bvh_info().n_wide_nodes, dtype=WIDE_NODE)
+        self._chk(lib().rt_read_bvh_wide(self._h, wide.ctypes.data, wide.nbytes))
+        return wide
 
 
 class _BorrowedContext(Context):

@@ -205,7 +205,7 @@ int rt_create(int device_ordinal, rt_ctx **out) {
         c->tune.uni_min = env("RT_TUNE_UNI_MIN", 16, 1, 65);
         c->tune.wide_vote_node = env("RT_TUNE_WIDE_VOTE_NODE", 3, 1, 64);
         c->tune.wide_vote_tri = env("RT_TUNE_WIDE_VOTE_TRI", 1, 1, 64);
-        c->tune_wide = env("RT_TUNE_WIDE", 0, 0, 1);
+        c->tune_wide = env("RT_TUNE_WIDE", 1, 0, 1);
     }
     int rc = RT_OK;
     do {
@@ -282,6 +282,7 @@ static void fill_info(rt_bvh_info *info, const RtBvhBuildResult &bvh, size_t n_m
     info->max_leaf = bvh.max_leaf;
     info->build_ms = bvh.build_ms;
     info->sah_cost = bvh.sah_cost;
+    info->n_wide_nodes = 0; info->wide_max_depth = 0; info->wide_stack_need = 0;
 }
 
 int rt_host_bvh_build(const rt_triangle *tris, size_t n_tris, const rt_mesh_info *meshes, size_t n_meshes,
@@ -437,6 +438,8 @@ int rt_upload_scene_ex(rt_ctx *c, const rt_triangle *tris, size_t n_tris, const 
     uint32_t nb = c->info.n_builds + 1, nr = c->info.n_refits;
     fill_info(&c->info, bvh, n_meshes, n_verts);
     c->info.n_builds = nb; c->info.n_refits = nr;
+    c->info.n_wide_nodes = c->wide_host.nodes.size();
+    c->info.wide_max_depth = c->wide_host.max_depth; c->info.wide_stack_need = c->wide_host.stack_need;
     c->h_tris.assign(tris, tris + n_tris);
     c->h_meshes.assign(meshes, meshes + n_meshes);
     c->bvh_host = std::move(bvh);
@@ -469,6 +472,10 @@ int rt_update_vertices(rt_ctx *c, const rt_vertex *verts, size_t n_verts, const 
         const RtBvhBuildResult &b = c->bvh_host;
         if (!b.nodes.empty()) HIPCHK(c, hipMemcpyAsync(c->d_nodes, b.nodes.data(), b.nodes.size() * sizeof(RtBvhNode), hipMemcpyHostToDevice, c->stream));
         if (!b.recs.empty()) HIPCHK(c, hipMemcpyAsync(c->d_recs, b.recs.data(), b.recs.size() * sizeof(RtTriRecord), hipMemcpyHostToDevice, c->stream));
+        if (!c->wide_host.nodes.empty()) {
+            rt_wide_requantise(b, &c->wide_host);
+            HIPCHK(c, hipMemcpyAsync(c->d_wide, c->wide_host.nodes.data(), c->wide_host.nodes.size() * sizeof(RtWideNode), hipMemcpyHostToDevice, c->stream));
+        }
         if (n_verts) HIPCHK(c, hipMemcpyAsync(c->d_verts, verts, n_verts * sizeof(rt_vertex), hipMemcpyHostToDevice, c->stream));
         if (n_meshes) HIPCHK(c, hipMemcpyAsync(c->d_meshes, meshes, n_meshes * sizeof(rt_mesh_info), hipMemcpyHostToDevice, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));   // host arrays are borrowed for this call only
@@ -494,6 +501,9 @@ int rt_update_vertices(rt_ctx *c, const rt_vertex *verts, size_t n_verts, const 
                                              (const rt_vertex *)c->d_verts, (const uint32_t *)c->d_level_nodes + off, cnt));
             off += cnt;
         }
+        // the wide tree's boxes are re-quantised from the refitted binary boxes (its topology does not change)
+        HIPCHK(c, rtk_launch_wide_requant(c->stream, (const RtBvhNode *)c->d_nodes, (const RtWideSrc *)c->d_wide_src,
+                                          (RtWideNode *)c->d_wide, c->S.n_wide));
         HIPCHK(c, hipEventRecord(e1, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));   // host arrays are borrowed for this call only
         float ms = 0.0f;
@@ -502,7 +512,6 @@ int rt_update_vertices(rt_ctx *c, const rt_vertex *verts, size_t n_verts, const 
         refit_ms = ms;
         c->bvh_host_stale = true;
     }
-    c->S.n_wide = 0;                              // TODO(wide): re-quantise after the refit
     c->h_meshes.assign(meshes, meshes + n_meshes);
     c->info.build_ms = refit_ms;
     c->info.n_refits += 1;
@@ -737,6 +746,17 @@ int rt_read_bvh(rt_ctx *c, void *nodes, size_t node_bytes_total, void *tris, siz
     HIPCHK(c, hipSetDevice(c->device));
     if (nodes && node_bytes_total) HIPCHK(c, hipMemcpyAsync(nodes, c->d_nodes, node_bytes_total, hipMemcpyDeviceToHost, c->stream));
     if (tris && tri_bytes_total) HIPCHK(c, hipMemcpyAsync(tris, c->d_recs, tri_bytes_total, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return RT_OK;
+}
+
+int rt_read_bvh_wide(rt_ctx *c, void *wide_nodes, size_t bytes_total) {
+    if (!c) return RT_ERR_ARG;
+    if (!c->has_scene) return RT_NOT_READY;
+    if (bytes_total != (size_t)c->S.n_wide * sizeof(RtWideNode))
+        return fail(c, RT_ERR_ARG, "rt_read_bvh_wide: buffer size must be n_wide_nodes * 64");
+    HIPCHK(c, hipSetDevice(c->device));
+    if (wide_nodes && bytes_total) HIPCHK(c, hipMemcpyAsync(wide_nodes, c->d_wide, bytes_total, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return RT_OK;
 }

@@ -42,6 +42,9 @@ hipError_t rtk_launch_path_bounce(hipStream_t st, const RtSceneDev &S, uint32_t 
 hipError_t rtk_launch_refit_level(hipStream_t st, RtBvhNode *nodes, RtTriRecord *recs, const rt_triangle *tris,
                                   const rt_vertex *verts, const uint32_t *level_nodes, uint32_t n);
 
+// after a refit: every wide node's child boxes re-quantised from the binary tree's boxes (rt_wide.h)
+hipError_t rtk_launch_wide_requant(hipStream_t st, const RtBvhNode *nodes, const RtWideSrc *src, RtWideNode *wide, uint32_t n);
+
 hipError_t rtk_launch_resolve(hipStream_t st, const float *accum, float *rgba, size_t n_px, float inv_unused,
                               uint32_t total_samples);
 hipError_t rtk_launch_encode_bgra8(hipStream_t st, const float *rgba, uint8_t *bgra, size_t n_px);

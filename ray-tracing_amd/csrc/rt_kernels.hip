@@ -7,6 +7,7 @@
 //   '/' and sqrtf are correctly rounded (hipcc default); min/max = fminf/fmaxf.
 #include <hip/hip_runtime.h>
 #include "rt_kernels.h"
+#include "rt_wide.h"
 
 // Per-lane traversal stack: the first RT_STACK_LDS entries live in LDS (stack[level][thread], bank
 // = lane: conflict-free), deeper levels spill to a private array.  16 entries x 256 threads = 16 KiB
@@ -125,6 +126,92 @@ __device__ __forceinline__ void stack_push(int &sp, lds_int *stk, prv_int *ovf, 
 }
 
 
+// One node step: the two child boxes of the fetched node against the lane's ray, then descend / push / pop.
+// Q: float4 (per-lane vector fetch) or q4 (one scalar fetch for the whole wave, operands in SGPRs).
+template <class Q>
+__device__ __forceinline__ void node_decide(Q q0, Q q1, Q q2, Q q3, f3 o, f3 inv, float t, int &cur, int &sp, lds_int *stk,
+                                            prv_int *ovf) {
+    const float limit = t * 1.00001f;   // relaxed bound: near-ties are still visited, seq decides
+    float ax0 = (q0.x - o.x) * inv.x, ax1 = (q0.w - o.x) * inv.x;
+    float ay0 = (q0.y - o.y) * inv.y, ay1 = (q1.x - o.y) * inv.y;
+    float az0 = (q0.z - o.z) * inv.z, az1 = (q1.y - o.z) * inv.z;
+    float bx0 = (q1.z - o.x) * inv.x, bx1 = (q2.y - o.x) * inv.x;
+    float by0 = (q1.w - o.y) * inv.y, by1 = (q2.z - o.y) * inv.y;
+    float bz0 = (q2.x - o.z) * inv.z, bz1 = (q2.w - o.z) * inv.z;
+    float tmin0 = fmaxf(fmaxf(fminf(ax0, ax1), fminf(ay0, ay1)), fminf(az0, az1));
+    float tmax0 = fminf(fminf(fmaxf(ax0, ax1), fmaxf(ay0, ay1)), fmaxf(az0, az1));
+    float tmin1 = fmaxf(fmaxf(fminf(bx0, bx1), fminf(by0, by1)), fminf(bz0, bz1));
+    float tmax1 = fminf(fminf(fmaxf(bx0, bx1), fmaxf(by0, by1)), fmaxf(bz0, bz1));
+    tmax0 *= 1.0000005f; tmax1 *= 1.0000005f;   // robust slab test (2 ulp)
+    bool h0 = tmin0 <= tmax0 && tmax0 >= 0.0f && tmin0 <= limit;
+    bool h1 = tmin1 <= tmax1 && tmax1 >= 0.0f && tmin1 <= limit;
+    int c0 = __float_as_int(q3.x), c1 = __float_as_int(q3.y);
+    bool both = h0 && h1;
+    bool swap = tmin1 < tmin0;
+    if (both) stack_push(sp, stk, ovf, swap ? c0 : c1);
+    if (h0 || h1) cur = (both ? swap : h1) ? c1 : c0;
+    else cur = stack_pop(sp, stk, ovf);
+}
+
+// One step on the 4-wide tree: four quantised child boxes against the lane's ray, the hit ones sorted by entry
+// distance, nearest taken, the others pushed farthest first.  Plane = org + byte*scl, so with A = scl*inv and
+// B = (o - org)*inv the slab distance is ONE fma per plane: byte*A - B (NaN / inf from a zero direction component
+// are dropped by min/max, i.e. the axis does not constrain -- conservative).  The boxes contain the binary tree's
+// (rt_wide.h), the far distance gets 8 ulp of relative slack for the rounding of this form with a distant origin.
+// The wide step's  byte*A - B  form cannot use an infinite 1/d (inf - inf): a direction component of (nearly) zero
+// gets +-1e30 instead -- the ray then drifts 1e-30 per unit of t on that axis, far inside the 1e-12 every box is
+// padded with (rt_wide.h).  The per-mesh cull of wgsl:155 still takes the exact 1/d.
+#define RT_WIDE_INV_MAX 1e30f
+template <bool WIDE>
+__device__ __forceinline__ f3 ray_inv(f3 d) {
+    f3 inv = F3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    if (WIDE) inv = F3(fminf(fmaxf(inv.x, -RT_WIDE_INV_MAX), RT_WIDE_INV_MAX), fminf(fmaxf(inv.y, -RT_WIDE_INV_MAX), RT_WIDE_INV_MAX),
+                       fminf(fmaxf(inv.z, -RT_WIDE_INV_MAX), RT_WIDE_INV_MAX));
+    return inv;
+}
+__device__ __forceinline__ float ub(uint32_t w, int k) { return (float)((w >> (8 * k)) & 0xFFu); }   // v_cvt_f32_ubyteK
+template <class Q>
+__device__ __forceinline__ void wide_decide(Q q0, Q q1, Q q2, Q q3, f3 o, f3 inv, float t, int &cur, int &sp, lds_int *stk,
+                                            prv_int *ovf) {
+    const float limit = t * 1.00001f;   // relaxed bound: near-ties are still visited, seq decides
+    const float Ax = q0.w * inv.x, Ay = q1.x * inv.y, Az = q1.y * inv.z;
+    const float Bx = (o.x - q0.x) * inv.x, By = (o.y - q0.y) * inv.y, Bz = (o.z - q0.z) * inv.z;
+    const uint32_t lox = __float_as_uint(q1.z), loy = __float_as_uint(q1.w), loz = __float_as_uint(q2.x);
+    const uint32_t hix = __float_as_uint(q2.y), hiy = __float_as_uint(q2.z), hiz = __float_as_uint(q2.w);
+    const bool sx = inv.x < 0.0f, sy = inv.y < 0.0f, sz = inv.z < 0.0f;
+    const uint32_t nx = sx ? hix : lox, fx = sx ? lox : hix;
+    const uint32_t ny = sy ? hiy : loy, fy = sy ? loy : hiy;
+    const uint32_t nz = sz ? hiz : loz, fz = sz ? loz : hiz;
+    uint32_t key[4]; int ref[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        float tn = fmaxf(fmaxf(__builtin_fmaf(ub(nx, k), Ax, -Bx), __builtin_fmaf(ub(ny, k), Ay, -By)), __builtin_fmaf(ub(nz, k), Az, -Bz));
+        float tf = fminf(fminf(__builtin_fmaf(ub(fx, k), Ax, -Bx), __builtin_fmaf(ub(fy, k), Ay, -By)), __builtin_fmaf(ub(fz, k), Az, -Bz));
+        tn = fmaxf(tn, 0.0f);
+        tf = fminf(tf * 1.000001f, limit);
+        const int c = __float_as_int(k == 0 ? q3.x : (k == 1 ? q3.y : (k == 2 ? q3.z : q3.w)));
+        const bool hit = tn <= tf && c != RT_CHILD_NONE;
+        key[k] = hit ? __float_as_uint(tn) : 0xFFFFFFFFu;      // tn >= 0: its bits order like the value
+        ref[k] = hit ? c : RT_CHILD_NONE;
+    }
+#define RT_CE(a, b) { const bool s_ = key[b] < key[a]; const uint32_t ka = s_ ? key[b] : key[a], kb = s_ ? key[a] : key[b]; \
+                      const int ra = s_ ? ref[b] : ref[a], rb = s_ ? ref[a] : ref[b]; key[a] = ka; key[b] = kb; ref[a] = ra; ref[b] = rb; }
+    RT_CE(0, 1) RT_CE(2, 3) RT_CE(0, 2) RT_CE(1, 3) RT_CE(1, 2)
+#undef RT_CE
+    if (sp + 3 <= RT_STACK_LDS) {      // the usual case: three slots left in the LDS part
+        if (ref[3] != RT_CHILD_NONE) { stk[sp * RT_BLOCK] = ref[3]; ++sp; }
+        if (ref[2] != RT_CHILD_NONE) { stk[sp * RT_BLOCK] = ref[2]; ++sp; }
+        if (ref[1] != RT_CHILD_NONE) { stk[sp * RT_BLOCK] = ref[1]; ++sp; }
+    } else {
+        if (ref[3] != RT_CHILD_NONE) stack_push(sp, stk, ovf, ref[3]);
+        if (ref[2] != RT_CHILD_NONE) stack_push(sp, stk, ovf, ref[2]);
+        if (ref[1] != RT_CHILD_NONE) stack_push(sp, stk, ovf, ref[1]);
+    }
+    if (ref[0] != RT_CHILD_NONE) cur = ref[0];
+    else cur = stack_pop(sp, stk, ovf);
+}
+
+
 // ---- BVH traversal (build-side design; reference src/bvh.rs:1 is empty) ----------------------
 // Closest hit with the reference's tie rule restated order-independently: among equal t the
 // lowest position in the (mesh, triangle) loop order wins (ray_tracing.wgsl:164).
@@ -141,12 +228,13 @@ __device__ __forceinline__ void stack_push(int &sp, lds_int *stk, prv_int *ovf, 
 // triangle step as soon as a quarter of the unfinished rays wait at a leaf -- early hits shorten
 // everything that follows.)
 // All lanes that call this must call it together (it counts them with a ballot).
-template <bool ANY, bool COUNT>
+template <bool ANY, bool COUNT, bool WIDE>
 __device__ __forceinline__ void traverse(const RtSceneDev &S, f3 o, f3 d, uint32_t flags, int *stk_generic, Hit &h, Cnt &c,
                                          uint32_t vote_node = 3u, uint32_t vote_tri = 1u) {
     h.hit = false; h.t = RT_INF; h.u = 0.0f; h.v = 0.0f; h.seq = 0xFFFFFFFFu; h.tri = 0xFFFFFFFFu; h.mesh = 0;
     if (S.n_nodes == 0) return;
-    const f3 inv = F3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    const f3 inv = ray_inv<WIDE>(d);
+    const RtBvhNode *const nodes = WIDE ? reinterpret_cast<const RtBvhNode *>(S.wide) : S.nodes;   // both 64 B
     lds_int *stk = (lds_int *)stk_generic;
     int ovf_mem[RT_STACK_OVF];
     prv_int *ovf = (prv_int *)ovf_mem;
@@ -160,30 +248,11 @@ __device__ __forceinline__ void traverse(const RtSceneDev &S, f3 o, f3 d, uint32
         const uint32_t n_leaf = n_all - n_done - n_node;
         if (n_node * vote_tri >= n_leaf * vote_node) {
             if (cur >= 0) {
-                const float4 *p = reinterpret_cast<const float4 *>(S.nodes + cur);
+                const float4 *p = reinterpret_cast<const float4 *>(nodes + cur);
                 float4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3];
                 if (COUNT) { c.nodes++; if ((threadIdx.x & 63u) == (uint32_t)__builtin_ctzll(m_node)) { c.wnodes++; c.walive += n_node + n_leaf; } }
-                const float limit = h.t * 1.00001f;   // relaxed bound: near-ties are still visited, seq decides
-                // slabs of both children; (plane - o) * inv keeps inf/NaN handling conservative
-                float ax0 = (q0.x - o.x) * inv.x, ax1 = (q0.w - o.x) * inv.x;
-                float ay0 = (q0.y - o.y) * inv.y, ay1 = (q1.x - o.y) * inv.y;
-                float az0 = (q0.z - o.z) * inv.z, az1 = (q1.y - o.z) * inv.z;
-                float bx0 = (q1.z - o.x) * inv.x, bx1 = (q2.y - o.x) * inv.x;
-                float by0 = (q1.w - o.y) * inv.y, by1 = (q2.z - o.y) * inv.y;
-                float bz0 = (q2.x - o.z) * inv.z, bz1 = (q2.w - o.z) * inv.z;
-                float tmin0 = fmaxf(fmaxf(fminf(ax0, ax1), fminf(ay0, ay1)), fminf(az0, az1));
-                float tmax0 = fminf(fminf(fmaxf(ax0, ax1), fmaxf(ay0, ay1)), fmaxf(az0, az1));
-                float tmin1 = fmaxf(fmaxf(fminf(bx0, bx1), fminf(by0, by1)), fminf(bz0, bz1));
-                float tmax1 = fminf(fminf(fmaxf(bx0, bx1), fmaxf(by0, by1)), fmaxf(bz0, bz1));
-                tmax0 *= 1.0000005f; tmax1 *= 1.0000005f;   // robust slab test (2 ulp)
-                bool h0 = tmin0 <= tmax0 && tmax0 >= 0.0f && tmin0 <= limit;
-                bool h1 = tmin1 <= tmax1 && tmax1 >= 0.0f && tmin1 <= limit;
-                int c0 = __float_as_int(q3.x), c1 = __float_as_int(q3.y);
-                bool both = h0 && h1;
-                bool swap = tmin1 < tmin0;
-                if (both) stack_push(sp, stk, ovf, swap ? c0 : c1);
-                if (h0 || h1) cur = (both ? swap : h1) ? c1 : c0;
-                else cur = stack_pop(sp, stk, ovf);
+                if (WIDE) wide_decide(q0, q1, q2, q3, o, inv, h.t, cur, sp, stk, ovf);
+                else node_decide(q0, q1, q2, q3, o, inv, h.t, cur, sp, stk, ovf);
             }
         } else {
             if (cur < 0 && cur != RT_DONE) {
@@ -202,7 +271,7 @@ __device__ __forceinline__ void traverse(const RtSceneDev &S, f3 o, f3 d, uint32
                     if (ok && !(flags & RT_FLAG_NO_MESH_CULL) && mesh != RT_REC_SPHERE) {   // per-mesh AABB cull of wgsl:155
                         const float4 *mp = reinterpret_cast<const float4 *>(S.meshes + mesh);
                         float4 m1 = mp[1], m2 = mp[2];
-                        ok = ray_aabb_ref(o, inv, F3(m1.x, m1.y, m1.z), F3(m2.x, m2.y, m2.z));
+                        ok = ray_aabb_ref(o, WIDE ? ray_inv<false>(d) : inv, F3(m1.x, m1.y, m1.z), F3(m2.x, m2.y, m2.z));
                         if (COUNT) c.meshes++;
                     }
                     if (ok) {
@@ -371,7 +440,8 @@ __device__ __forceinline__ void brute_force(const RtSceneDev &S, f3 o, f3 d, uin
 template <bool ANY, bool COUNT>
 __device__ __forceinline__ void trace(const RtSceneDev &S, f3 o, f3 d, uint32_t flags, int *stk, Hit &h, Cnt &c) {
     if (flags & RT_FLAG_BRUTE_FORCE) brute_force<ANY, COUNT>(S, o, d, flags, h, c);
-    else traverse<ANY, COUNT>(S, o, d, flags, stk, h, c);
+    else if (S.n_wide != 0u && !(flags & RT_FLAG_BINARY_TREE)) traverse<ANY, COUNT, true>(S, o, d, flags, stk, h, c);   // kernel-uniform choice
+    else traverse<ANY, COUNT, false>(S, o, d, flags, stk, h, c);
 }
 
 // point and interpolated vertex normal of an accepted hit: ray_tracing.wgsl:137-138
@@ -547,91 +617,6 @@ __device__ __forceinline__ bool pixel_of_region(const RtViewDev &V, const RtShar
     uint32_t yy = gy * sh.tile + (quad / sub) * 16u + (b >> 1) * 8u + (w >> 3);
     px = V.vx + xx; py = V.vy + yy;
     return xx < V.vw && yy < V.vh;
-}
-
-// One node step: the two child boxes of the fetched node against the lane's ray, then descend / push / pop.
-// Q: float4 (per-lane vector fetch) or q4 (one scalar fetch for the whole wave, operands in SGPRs).
-template <class Q>
-__device__ __forceinline__ void node_decide(Q q0, Q q1, Q q2, Q q3, f3 o, f3 inv, float t, int &cur, int &sp, lds_int *stk,
-                                            prv_int *ovf) {
-    const float limit = t * 1.00001f;   // relaxed bound: near-ties are still visited, seq decides
-    float ax0 = (q0.x - o.x) * inv.x, ax1 = (q0.w - o.x) * inv.x;
-    float ay0 = (q0.y - o.y) * inv.y, ay1 = (q1.x - o.y) * inv.y;
-    float az0 = (q0.z - o.z) * inv.z, az1 = (q1.y - o.z) * inv.z;
-    float bx0 = (q1.z - o.x) * inv.x, bx1 = (q2.y - o.x) * inv.x;
-    float by0 = (q1.w - o.y) * inv.y, by1 = (q2.z - o.y) * inv.y;
-    float bz0 = (q2.x - o.z) * inv.z, bz1 = (q2.w - o.z) * inv.z;
-    float tmin0 = fmaxf(fmaxf(fminf(ax0, ax1), fminf(ay0, ay1)), fminf(az0, az1));
-    float tmax0 = fminf(fminf(fmaxf(ax0, ax1), fmaxf(ay0, ay1)), fmaxf(az0, az1));
-    float tmin1 = fmaxf(fmaxf(fminf(bx0, bx1), fminf(by0, by1)), fminf(bz0, bz1));
-    float tmax1 = fminf(fminf(fmaxf(bx0, bx1), fmaxf(by0, by1)), fmaxf(bz0, bz1));
-    tmax0 *= 1.0000005f; tmax1 *= 1.0000005f;   // robust slab test (2 ulp)
-    bool h0 = tmin0 <= tmax0 && tmax0 >= 0.0f && tmin0 <= limit;
-    bool h1 = tmin1 <= tmax1 && tmax1 >= 0.0f && tmin1 <= limit;
-    int c0 = __float_as_int(q3.x), c1 = __float_as_int(q3.y);
-    bool both = h0 && h1;
-    bool swap = tmin1 < tmin0;
-    if (both) stack_push(sp, stk, ovf, swap ? c0 : c1);
-    if (h0 || h1) cur = (both ? swap : h1) ? c1 : c0;
-    else cur = stack_pop(sp, stk, ovf);
-}
-
-// One step on the 4-wide tree: four quantised child boxes against the lane's ray, the hit ones sorted by entry
-// distance, nearest taken, the others pushed farthest first.  Plane = org + byte*scl, so with A = scl*inv and
-// B = (o - org)*inv the slab distance is ONE fma per plane: byte*A - B (NaN / inf from a zero direction component
-// are dropped by min/max, i.e. the axis does not constrain -- conservative).  The boxes contain the binary tree's
-// (rt_wide.h), the far distance gets 8 ulp of relative slack for the rounding of this form with a distant origin.
-// The wide step's  byte*A - B  form cannot use an infinite 1/d (inf - inf): a direction component of (nearly) zero
-// gets +-1e30 instead -- the ray then drifts 1e-30 per unit of t on that axis, far inside the 1e-12 every box is
-// padded with (rt_wide.h).  The per-mesh cull of wgsl:155 still takes the exact 1/d.
-#define RT_WIDE_INV_MAX 1e30f
-template <bool WIDE>
-__device__ __forceinline__ f3 ray_inv(f3 d) {
-    f3 inv = F3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-    if (WIDE) inv = F3(fminf(fmaxf(inv.x, -RT_WIDE_INV_MAX), RT_WIDE_INV_MAX), fminf(fmaxf(inv.y, -RT_WIDE_INV_MAX), RT_WIDE_INV_MAX),
-                       fminf(fmaxf(inv.z, -RT_WIDE_INV_MAX), RT_WIDE_INV_MAX));
-    return inv;
-}
-__device__ __forceinline__ float ub(uint32_t w, int k) { return (float)((w >> (8 * k)) & 0xFFu); }   // v_cvt_f32_ubyteK
-template <class Q>
-__device__ __forceinline__ void wide_decide(Q q0, Q q1, Q q2, Q q3, f3 o, f3 inv, float t, int &cur, int &sp, lds_int *stk,
-                                            prv_int *ovf) {
-    const float limit = t * 1.00001f;   // relaxed bound: near-ties are still visited, seq decides
-    const float Ax = q0.w * inv.x, Ay = q1.x * inv.y, Az = q1.y * inv.z;
-    const float Bx = (o.x - q0.x) * inv.x, By = (o.y - q0.y) * inv.y, Bz = (o.z - q0.z) * inv.z;
-    const uint32_t lox = __float_as_uint(q1.z), loy = __float_as_uint(q1.w), loz = __float_as_uint(q2.x);
-    const uint32_t hix = __float_as_uint(q2.y), hiy = __float_as_uint(q2.z), hiz = __float_as_uint(q2.w);
-    const bool sx = inv.x < 0.0f, sy = inv.y < 0.0f, sz = inv.z < 0.0f;
-    const uint32_t nx = sx ? hix : lox, fx = sx ? lox : hix;
-    const uint32_t ny = sy ? hiy : loy, fy = sy ? loy : hiy;
-    const uint32_t nz = sz ? hiz : loz, fz = sz ? loz : hiz;
-    uint32_t key[4]; int ref[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        float tn = fmaxf(fmaxf(__builtin_fmaf(ub(nx, k), Ax, -Bx), __builtin_fmaf(ub(ny, k), Ay, -By)), __builtin_fmaf(ub(nz, k), Az, -Bz));
-        float tf = fminf(fminf(__builtin_fmaf(ub(fx, k), Ax, -Bx), __builtin_fmaf(ub(fy, k), Ay, -By)), __builtin_fmaf(ub(fz, k), Az, -Bz));
-        tn = fmaxf(tn, 0.0f);
-        tf = fminf(tf * 1.000001f, limit);
-        const int c = __float_as_int(k == 0 ? q3.x : (k == 1 ? q3.y : (k == 2 ? q3.z : q3.w)));
-        const bool hit = tn <= tf && c != RT_CHILD_NONE;
-        key[k] = hit ? __float_as_uint(tn) : 0xFFFFFFFFu;      // tn >= 0: its bits order like the value
-        ref[k] = hit ? c : RT_CHILD_NONE;
-    }
-#define RT_CE(a, b) { const bool s_ = key[b] < key[a]; const uint32_t ka = s_ ? key[b] : key[a], kb = s_ ? key[a] : key[b]; \
-                      const int ra = s_ ? ref[b] : ref[a], rb = s_ ? ref[a] : ref[b]; key[a] = ka; key[b] = kb; ref[a] = ra; ref[b] = rb; }
-    RT_CE(0, 1) RT_CE(2, 3) RT_CE(0, 2) RT_CE(1, 3) RT_CE(1, 2)
-#undef RT_CE
-    if (sp + 3 <= RT_STACK_LDS) {      // the usual case: three slots left in the LDS part
-        if (ref[3] != RT_CHILD_NONE) { stk[sp * RT_BLOCK] = ref[3]; ++sp; }
-        if (ref[2] != RT_CHILD_NONE) { stk[sp * RT_BLOCK] = ref[2]; ++sp; }
-        if (ref[1] != RT_CHILD_NONE) { stk[sp * RT_BLOCK] = ref[1]; ++sp; }
-    } else {
-        if (ref[3] != RT_CHILD_NONE) stack_push(sp, stk, ovf, ref[3]);
-        if (ref[2] != RT_CHILD_NONE) stack_push(sp, stk, ovf, ref[2]);
-        if (ref[1] != RT_CHILD_NONE) stack_push(sp, stk, ovf, ref[1]);
-    }
-    if (ref[0] != RT_CHILD_NONE) cur = ref[0];
-    else cur = stack_pop(sp, stk, ovf);
 }
 
 template <bool COUNT, bool WIDE>
@@ -1128,6 +1113,19 @@ hipError_t rtk_launch_refit_level(hipStream_t st, RtBvhNode *nodes, RtTriRecord 
                                   const rt_vertex *verts, const uint32_t *level_nodes, uint32_t n) {
     if (n == 0) return hipSuccess;
     hipLaunchKernelGGL(k_refit_level, dim3((n + 255) / 256), dim3(256), 0, st, nodes, recs, tris, verts, level_nodes, n);
+    return hipGetLastError();
+}
+
+__global__ void k_wide_requant(const RtBvhNode *__restrict__ nodes, const RtWideSrc *__restrict__ src, RtWideNode *wide, uint32_t n) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    RtWideNode W = wide[i];
+    rt_wide_quantise(nodes, src[i], W);
+    wide[i] = W;
+}
+hipError_t rtk_launch_wide_requant(hipStream_t st, const RtBvhNode *nodes, const RtWideSrc *src, RtWideNode *wide, uint32_t n) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_wide_requant, dim3((n + 255) / 256), dim3(256), 0, st, nodes, src, wide, n);
     return hipGetLastError();
 }
 

@@ -22,7 +22,8 @@ def _golden(name):
 
 
 @pytest.mark.parametrize("name", ["default_64x36_shadow", "spheres8_48x32"])
-@pytest.mark.parametrize("extra", [0, rt.FLAG_WAVE_TRAVERSAL, rt.FLAG_STATIC_GRID, rt.FLAG_BRUTE_FORCE])
+@pytest.mark.parametrize("extra", [0, rt.FLAG_BINARY_TREE, rt.FLAG_WAVE_TRAVERSAL, rt.FLAG_STATIC_GRID, rt.FLAG_STATIC_GRID | rt.FLAG_BINARY_TREE,
+                                   rt.FLAG_BRUTE_FORCE])
 def test_golden_fixtures(name, extra):
     g, scene, W, H = _golden(name)
     with rt.Context(0) as ctx:
@@ -34,9 +35,9 @@ def test_golden_fixtures(name, extra):
         assert bitwise_equal(ctx.read_radiance(), g["rgba"])
         c = ctx.counters()
         assert c.rays_primary + c.rays_shadow == int(g["rays"])
-        if "path_accum" in g and not extra:
+        if "path_accum" in g and extra in (0, rt.FLAG_BINARY_TREE):
             spp = int(g["path_spp"])
-            assert ctx.render(flags=rt.FLAG_PATH_TRACE, spp=spp, max_segments=4, seed=int(g["path_seed"])) == rt.RT_OK
+            assert ctx.render(flags=rt.FLAG_PATH_TRACE | extra, spp=spp, max_segments=4, seed=int(g["path_seed"])) == rt.RT_OK
             assert bitwise_equal(ctx.read_accumulation(), g["path_accum"])
             c = ctx.counters()
             assert c.rays_primary + c.rays_bounce == int(g["path_segments"])
@@ -190,6 +191,23 @@ def test_update_vertices_refit_matches_a_rebuild_and_rejects_other_topologies():
         _, nodes_h, recs_h = rt.host_bvh_build(scene, threads=2, refit_to=moved)
         nodes_g, recs_g = ctx.read_bvh()
         assert bitwise_equal(nodes_g, nodes_h) and bitwise_equal(recs_g, recs_h)
+        # ... and the 4-wide tree re-quantised on the device equals the one re-quantised on the host (same topology,
+        # the boxes of the refitted binary tree): a second context takes the host refit path
+        wide_g = ctx.read_bvh_wide()
+        assert len(wide_g) == ctx.bvh_info().n_wide_nodes > 0
+        os.environ["RT_TUNE_HOST_REFIT"] = "1"
+        try:
+            with rt.Context(0) as ctx2:
+                ctx2.upload_scene(scene)
+                wide_0 = ctx2.read_bvh_wide()
+                ctx2.update_vertices(moved)
+                wide_h = ctx2.read_bvh_wide()
+        finally:
+            del os.environ["RT_TUNE_HOST_REFIT"]
+        assert bitwise_equal(wide_g, wide_h) and not bitwise_equal(wide_h, wide_0)
+        assert np.array_equal(wide_h["child"], wide_0["child"])                   # topology kept
+        assert ctx.render(flags=rt.FLAG_SHADOW | rt.FLAG_BINARY_TREE) == rt.RT_OK # both trees give the oracle's frame
+        assert bitwise_equal(ctx.read_prim_ids(), prim_o) and bitwise_equal(ctx.read_radiance(), rgba_o)
         bad = rt.Scene(scene.triangles, moved.meshes, moved.vertices.copy(), scene.materials)
         bad.vertices["pos"][int(moved.triangles["indices"][0][0])] = np.nan       # a non-finite vertex needs a rebuild
         with pytest.raises(rt.RtError) as e:
@@ -200,6 +218,41 @@ def test_update_vertices_refit_matches_a_rebuild_and_rejects_other_topologies():
         with pytest.raises(rt.RtError) as e:
             ctx.update_vertices(fewer)
         assert e.value.status == rt.RT_ERR_SCENE
+
+
+@pytest.mark.parametrize("kind", ["default", "soup", "analytic"])
+def test_wide_and_binary_trees_give_identical_results(kind):
+    """The 4-wide quantised tree (default) and the binary tree it was collapsed from (RT_FLAG_BINARY_TREE): the same
+    primitive, distance and radiance in every pixel, for every kernel that walks a tree, with about half the node visits."""
+    if kind == "default":
+        app = default_app(320, 180)
+        scene = app.prepare_meshinfo()
+    elif kind == "soup":
+        app = soup_app(60, 0x5EED0003, 320, 180, subdivisions=3)
+        app.camera_frame_scene(1.0)
+        scene = app.prepare_meshinfo()
+    else:
+        scene = rt.analytic_sphere_field(500, 0x5EED0002)
+        app = default_app(320, 180)
+        app.camera_look_at((60.0, 30.0, 60.0), (0, 5, 0), (0, 1, 0))
+    m, p = app.camera_view()
+    with rt.Context(0) as ctx:
+        ctx.upload_scene(scene)
+        ctx.set_view(m, p, 320, 180)
+        assert ctx.bvh_info().n_wide_nodes > 0
+        for flags in (rt.FLAG_SHADOW, rt.FLAG_SHADOW | rt.FLAG_STATIC_GRID, 0):
+            out = []
+            for tree in (0, rt.FLAG_BINARY_TREE):
+                assert ctx.render(flags=flags | tree | rt.FLAG_COUNTERS) == rt.RT_OK
+                out.append((ctx.read_prim_ids(), ctx.read_hit_t(), ctx.read_radiance(), ctx.counters()))
+            assert all(bitwise_equal(out[0][i], out[1][i]) for i in range(3))
+            assert out[0][3].rays_primary == out[1][3].rays_primary and out[0][3].rays_shadow == out[1][3].rays_shadow
+            assert out[0][3].node_visits < 0.75 * out[1][3].node_visits
+        acc = []
+        for tree in (0, rt.FLAG_BINARY_TREE):
+            assert ctx.render(flags=rt.FLAG_PATH_TRACE | tree, spp=2, max_segments=4, seed=5) == rt.RT_OK
+            acc.append((ctx.read_accumulation(), ctx.counters()))
+        assert bitwise_equal(acc[0][0], acc[1][0]) and acc[0][1].rays_bounce == acc[1][1].rays_bounce
 
 
 def test_edge_cases_empty_scene_not_ready_and_bad_arguments():

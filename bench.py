@@ -271,7 +271,7 @@ def main():
                                        (f"sample-slices{world}+allreduce" if samples else f"frames-dp{world}"))},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                         "kernel": ("k_path_start+k_path_bounce (whole frame)" if spp else "k_stream<false>"),
+                         "kernel": ("k_path_start+k_path_bounce (whole frame)" if spp else "k_stream<false, true>"),
                          "kernel_ms": round(kernel_ms, 4),
                          "algorithmic_bytes_per_launch": int(alg_bytes),
                          "node_visits": int(cnt.node_visits), "tri_tests": int(cnt.tri_tests),

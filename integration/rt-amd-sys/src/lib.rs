@@ -49,6 +49,7 @@ pub const RT_FLAG_ACCUMULATE: u32 = 0x0020;
 pub const RT_FLAG_TIME_KERNELS: u32 = 0x0040;
 pub const RT_FLAG_WAVE_TRAVERSAL: u32 = 0x0080;
 pub const RT_FLAG_STATIC_GRID: u32 = 0x0100;
+pub const RT_FLAG_BINARY_TREE: u32 = 0x0200;
 
 extern "C" {
     pub fn rt_create(device_ordinal: c_int, out: *mut *mut rt_ctx) -> c_int;

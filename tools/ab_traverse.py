@@ -13,6 +13,7 @@ def scene(kind):
     app.camera_set_target(1920, 1080)
     return app
 
+_ENV0 = {k: v for k, v in os.environ.items() if k.startswith("RT_TUNE_")}
 variants = []
 for extra in sys.argv[1:]:          # name:ENV=VAL,ENV=VAL:flag
     name, envs, fl = extra.split(":")
@@ -21,6 +22,8 @@ ref = {}
 for kind in ("field", "soup", "default"):
     app = scene(kind); sc = app.prepare_meshinfo(); m, p = app.camera_view()
     for name, env, fl in variants:
+        for k in [k for k in os.environ if k.startswith("RT_TUNE_") and k not in _ENV0]: del os.environ[k]
+        os.environ.update(_ENV0)            # every variant starts from the environment the script was given
         for k, v in env.items(): os.environ[k] = v
         ctx = rt.Context(0); ctx.upload_scene(sc); ctx.set_view(m, p, 1920, 1080)
         f = rt.FLAG_SHADOW | fl

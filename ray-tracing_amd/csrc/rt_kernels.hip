@@ -664,6 +664,9 @@ __global__ __launch_bounds__(RT_BLOCK, RT_MIN_WAVES) void k_stream(
 #ifdef RT_TRIP_LIMIT
     uint32_t dbg_trips = 0;
 #endif
+#ifdef RT_DEBUG_TIMELINE
+    const unsigned long long dbg_t0 = wall_clock64();
+#endif
     for (;;) {
         // ================= service: runs when the hot loop below asks for it =================================
         // ---- 1. finish ended rays (shade, write, start the shadow ray) -----------------------------------------
@@ -839,6 +842,13 @@ __global__ __launch_bounds__(RT_BLOCK, RT_MIN_WAVES) void k_stream(
 #endif
         } while (!(n_live == 0u || n_pend >= finish_min || (more && n_done >= refill_min)));
     }
+#ifdef RT_DEBUG_TIMELINE     // debug builds only (tools/timeline.py): per-wave start / end times (100 MHz) over the hit-distance output
+    if (lane == 0u) {
+        uint32_t wid = blockIdx.x * (RT_BLOCK / 64u) + (threadIdx.x >> 6);
+        reinterpret_cast<uint32_t *>(tout)[2u * wid] = (uint32_t)dbg_t0;
+        reinterpret_cast<uint32_t *>(tout)[2u * wid + 1u] = (uint32_t)wall_clock64();
+    }
+#endif
     wave_sum(counters + RT_CNT_PRIMARY, n_primary);
     wave_sum(counters + RT_CNT_SHADOW, n_shadow);
     if (COUNT) {

@@ -403,7 +403,15 @@ int rt_upload_scene_ex(rt_ctx *c, const rt_triangle *tris, size_t n_tris, const 
         c->level_count = count;
     }
     c->wide_host = RtWideTree();
-    if (c->tune_wide && !bvh.nodes.empty()) {
+    bool wide_ok = c->tune_wide && !bvh.nodes.empty();
+    if (wide_ok) {      // the root's two boxes bound every coordinate in the tree
+        const RtBvhNode &R = bvh.nodes[0];
+        for (int k = 0; k < 3; ++k) {
+            float ext[4] = {R.lo0[k], R.hi0[k], R.lo1[k], R.hi1[k]};
+            for (float v : ext) if (std::isfinite(v) ? std::fabs(v) >= RT_WIDE_COORD_MAX : !std::isnan(v)) wide_ok = false;
+        }
+    }
+    if (wide_ok) {
         try {
             rt_bvh_widen(bvh, &c->wide_host);
         } catch (const std::bad_alloc &) {
@@ -589,6 +597,8 @@ int rt_render(rt_ctx *c, const rt_render_params *params) {
                    ((uint64_t)c->V.vx << 5) ^ ((uint64_t)c->V.vy << 21) ^ ((uint64_t)c->V.vw << 37) ^
                    ((uint64_t)c->V.vh << 49) ^ (partial ? 0x8000000000000000ull : 0ull));
     bool path = (P.flags & RT_FLAG_PATH_TRACE) != 0;
+    for (int k = 0; k < 3; ++k)      // a camera beyond the wide step's coordinate range: binary tree (rt_layout.h)
+        if (!(std::fabs(c->V.pos[k]) < RT_WIDE_COORD_MAX)) P.flags |= RT_FLAG_BINARY_TREE;
     if (sig != c->coverage_sig) {
         int rc = clear_outputs(c);
         if (rc != RT_OK) return rc;

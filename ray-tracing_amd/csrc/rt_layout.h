@@ -41,6 +41,10 @@ static_assert(sizeof(RtWideNode) == 64, "wide node must be 64 B");
 // Where the four boxes of a wide node come from: (binary node index << 1) | child side; RT_WIDE_EMPTY = none.
 struct RtWideSrc { uint32_t slot[4]; };
 #define RT_WIDE_EMPTY 0xFFFFFFFFu
+// The wide step computes byte*(scl/d) - (o - org)/d with 1/d clamped to 1e30: every term stays finite only while the
+// coordinates do.  Scenes or camera positions beyond this magnitude are walked on the binary tree, whose
+// (plane - o)/d form has no such limit.
+#define RT_WIDE_COORD_MAX 5e7f
 
 // One leaf triangle record = 48 B, stored in BVH leaf order so a leaf is one contiguous run.
 // a, ab = b-a, ac = c-a are the exact f32 values ray_triangle computes first

@@ -255,6 +255,71 @@ def test_wide_and_binary_trees_give_identical_results(kind):
         assert bitwise_equal(acc[0][0], acc[1][0]) and acc[0][1].rays_bounce == acc[1][1].rays_bounce
 
 
+@pytest.mark.parametrize("case", ["far_camera", "tiny_scene_far_from_origin", "large_scene", "huge_coordinates", "huge_camera"])
+def test_wide_tree_conservative_culling_at_the_extremes(case):
+    """Where the wide step's byte*A - B form is least comfortable: an origin thousands of scene sizes away (its rounding
+    error scales with the distance), a small scene far from the world origin (the grid expansion scales with the
+    coordinates), a scene of millions of units, and -- beyond RT_WIDE_COORD_MAX, where the wide step's terms could overflow --
+    coordinates near FLT_MAX and a camera 1e9 away, which the library walks on the binary tree. Oracle == wide == binary."""
+    if case == "far_camera":
+        app = default_app(48, 48)
+        app.camera_set_projection(0.0008, 0.1)
+        app.camera_look_at((9000.0, 6000.0, 12000.0), (0, 0.5, 0), (0, 1, 0))
+        scene = app.prepare_meshinfo()
+    elif case == "tiny_scene_far_from_origin":
+        app = default_app(48, 48)
+        base = app.prepare_meshinfo()
+        v = base.vertices.copy()
+        v["pos"] = v["pos"] * np.float32(1e-3) + np.float32([4096.0, -2048.0, 1024.0])
+        m = base.meshes.copy()
+        m["aabb_min"] = m["aabb_min"] * np.float32(1e-3) + np.float32([4096.0, -2048.0, 1024.0])
+        m["aabb_max"] = m["aabb_max"] * np.float32(1e-3) + np.float32([4096.0, -2048.0, 1024.0])
+        scene = rt.Scene(base.triangles, m, v, base.materials)
+        app.camera_look_at((4096.0, -2047.997, 1024.005), (4096.0, -2048.0, 1024.0), (0, 1, 0))
+    elif case in ("large_scene", "huge_camera"):
+        app = default_app(48, 48)
+        base = app.prepare_meshinfo()
+        v = base.vertices.copy()
+        v["pos"] = v["pos"] * np.float32(1e6)
+        m = base.meshes.copy()
+        m["aabb_min"] = m["aabb_min"] * np.float32(1e6)
+        m["aabb_max"] = m["aabb_max"] * np.float32(1e6)
+        scene = rt.Scene(base.triangles, m, v, base.materials)
+        if case == "large_scene":
+            app.camera_look_at((0.0, 3e6, 5e6), (0, 0, 0), (0, 1, 0))
+        else:
+            app.camera_set_projection(0.06, 0.1)
+            app.camera_look_at((1.2e8, 0.8e8, 1.6e8), (0, 5e5, 0), (0, 1, 0))
+    else:
+        app = default_app(48, 48)
+        base = app.prepare_meshinfo()
+        nv = len(base.vertices)
+        v = np.concatenate([base.vertices, np.zeros(6, rt.VERTEX)])
+        v["pos"][nv:] = [(-3e38, 0, 0), (-3e38, 1, 0), (-3e38, 0, 1), (3e38, 0, 0), (3e38, 1, 0), (3e38, 0, 1)]
+        v["norm"][nv:] = (0, 1, 0)
+        t = np.concatenate([base.triangles, np.zeros(2, rt.TRIANGLE)])
+        t["indices"][-2:] = [(nv, nv + 1, nv + 2), (nv + 3, nv + 4, nv + 5)]
+        m = np.concatenate([base.meshes, np.zeros(1, rt.MESH_INFO)])
+        m["first_tri"][-1] = len(base.triangles)
+        m["tri_count"][-1] = 2
+        m["aabb_min"][-1] = (-3e38, 0, 0)
+        m["aabb_max"][-1] = (3e38, 1, 1)
+        scene = rt.Scene(t, m, v, base.materials)
+    rgba_o, prim_o, t_o, _ = orc.render_primary(oracle_scene(scene), oracle_view(app), orc.FLAG_SHADOW)
+    assert (prim_o != rt.MISS_PRIM).mean() > 0.2                     # the view does look at the scene
+    for tree in (0, rt.FLAG_BINARY_TREE):
+        ctx, rgba_g, prim_g, t_g = gpu_render(app, scene, rt.FLAG_SHADOW | tree | rt.FLAG_COUNTERS)
+        assert (ctx.bvh_info().n_wide_nodes > 0) == (case != "huge_coordinates")
+        if tree == 0:
+            visits_wide = ctx.counters().node_visits
+        elif case in ("huge_coordinates", "huge_camera"):
+            assert ctx.counters().node_visits == visits_wide            # both renders walked the binary tree
+        else:
+            assert ctx.counters().node_visits > visits_wide
+        assert bitwise_equal(prim_g, prim_o) and bitwise_equal(t_g, t_o) and bitwise_equal(rgba_g, rgba_o)
+        ctx.close()
+
+
 def test_edge_cases_empty_scene_not_ready_and_bad_arguments():
     with rt.Context(0) as ctx:
         assert ctx.render() == rt.RT_NOT_READY                     # no scene, no view

@@ -289,6 +289,24 @@ def main():
                 d = rgba_g.astype(np.float64) - rgba_o.astype(np.float64)
                 out["parity"] = {"prim_id_agreement": float((prim_g == prim_o).mean()),
                                  "radiance_rmse": float(np.sqrt(np.mean(d * d))), "pixels": int(len(pix))}
+        # second denominator: what a plain device-to-device copy reaches on THIS box, read + write bytes
+        try:
+            src = torch.empty(1 << 28, dtype=torch.float32, device="cuda")       # 1 GiB: beyond the 256 MiB Infinity Cache
+            dst = torch.empty_like(src)
+            dst.copy_(src)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(5):
+                dst.copy_(src)
+            e1.record()
+            torch.cuda.synchronize()
+            copy_gbs = 5 * 2 * src.numel() * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+            out["roofline"]["stream_copy_GBps"] = round(copy_gbs, 1)
+            out["roofline"]["frac_of_stream_copy"] = round(achieved / copy_gbs, 5)
+            del src, dst
+        except Exception as ex:                                                  # never fail the bench line for it
+            out["roofline"]["stream_copy_GBps"] = None
+            out["roofline"]["stream_copy_error"] = str(ex)[:80]
         print(json.dumps(out), flush=True)
     ctx.close()
     if world > 1:

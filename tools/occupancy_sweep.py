@@ -19,4 +19,4 @@ for name, n in scenes:
         for _ in range(20): ctx.render(flags=rt.FLAG_SHADOW | rt.FLAG_TIME_KERNELS)
         k = ctx.counters(); row.append("%d:%.3f" % (b, k.kernel_ms / k.kernel_launches))
         info = ctx.bvh_info(); ctx.close()
-    print(name, "bvh MB %.1f" % ((info.n_nodes * 64 + info.n_triangles * 48) / 1e6), " ".join(row), flush=True)
+    print(name, "binary MB %.1f walked (wide nodes + records) MB %.1f" % ((info.n_nodes * 64 + info.n_triangles * 48) / 1e6, (info.n_wide_nodes * 64 + info.n_triangles * 48) / 1e6), " ".join(row), flush=True)

@@ -169,6 +169,17 @@ __device__ __forceinline__ f3 ray_inv(f3 d) {
                        fminf(fmaxf(inv.z, -RT_WIDE_INV_MAX), RT_WIDE_INV_MAX));
     return inv;
 }
+// The exact 1/d for the per-mesh cull, from the clamped one: a component that was not clamped IS 1/d; only a clamped
+// one (a direction component of (nearly) zero) is divided again.  Keeps three registers out of the traversal loop.
+template <bool WIDE>
+__device__ __forceinline__ f3 exact_inv(f3 inv, f3 d) {
+    if (WIDE) {
+        if (!(fabsf(inv.x) < RT_WIDE_INV_MAX)) inv.x = 1.0f / d.x;
+        if (!(fabsf(inv.y) < RT_WIDE_INV_MAX)) inv.y = 1.0f / d.y;
+        if (!(fabsf(inv.z) < RT_WIDE_INV_MAX)) inv.z = 1.0f / d.z;
+    }
+    return inv;
+}
 __device__ __forceinline__ float ub(uint32_t w, int k) { return (float)((w >> (8 * k)) & 0xFFu); }   // v_cvt_f32_ubyteK
 template <class Q>
 __device__ __forceinline__ void wide_decide(Q q0, Q q1, Q q2, Q q3, f3 o, f3 inv, float t, int &cur, int &sp, lds_int *stk,
@@ -249,6 +260,7 @@ __device__ __forceinline__ void traverse(const RtSceneDev &S, f3 o, f3 d, uint32
     int sp = 0;
     int cur = 0;
     uint32_t n_done = 0;
+    uint32_t rec = 0xFFFFFFFFu;           // the accepted record: one register instead of hit flag + tri + mesh
     do {
         const unsigned long long m_node = __ballot(cur >= 0);
         const uint32_t n_node = (uint32_t)__builtin_popcountll(m_node);
@@ -278,13 +290,10 @@ __device__ __forceinline__ void traverse(const RtSceneDev &S, f3 o, f3 d, uint32
                     if (ok && !(flags & RT_FLAG_NO_MESH_CULL) && mesh != RT_REC_SPHERE) {   // per-mesh AABB cull of wgsl:155
                         const float4 *mp = reinterpret_cast<const float4 *>(S.meshes + mesh);
                         float4 m1 = mp[1], m2 = mp[2];
-                        ok = ray_aabb_ref(o, WIDE ? ray_inv<false>(d) : inv, F3(m1.x, m1.y, m1.z), F3(m2.x, m2.y, m2.z));
+                        ok = ray_aabb_ref(o, exact_inv<WIDE>(inv, d), F3(m1.x, m1.y, m1.z), F3(m2.x, m2.y, m2.z));
                         if (COUNT) c.meshes++;
                     }
-                    if (ok) {
-                        h.hit = true; h.t = dst; h.u = u; h.v = v; h.seq = seq;
-                        h.tri = __float_as_uint(r2.y); h.mesh = mesh;
-                    }
+                    if (ok) { h.t = dst; h.u = u; h.v = v; h.seq = seq; rec = first; }   // tri / mesh: read back from the record below
                     if (ok && ANY) cur = RT_DONE;
                     else if (left == 0u) cur = stack_pop(sp, stk, ovf);
                     else cur = ~(int)(((first + 1u) << 3) | (left - 1u));
@@ -293,6 +302,10 @@ __device__ __forceinline__ void traverse(const RtSceneDev &S, f3 o, f3 d, uint32
         }
         n_done = (uint32_t)__builtin_popcountll(__ballot(cur == RT_DONE));
     } while (n_done != n_all);
+    if (rec != 0xFFFFFFFFu) {
+        float4 r2 = reinterpret_cast<const float4 *>(S.recs + rec)[2];
+        h.hit = true; h.tri = __float_as_uint(r2.y); h.mesh = __float_as_uint(r2.z);
+    }
 }
 
 
@@ -817,7 +830,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_MIN_WAVES) void k_stream(
                         if (ok && !(flags & RT_FLAG_NO_MESH_CULL) && __float_as_uint(r2.z) != RT_REC_SPHERE) {   // per-mesh AABB cull of wgsl:155
                             const float4 *mp = reinterpret_cast<const float4 *>(meshes + __float_as_uint(r2.z));
                             float4 m1 = mp[1], m2 = mp[2];
-                            ok = ray_aabb_ref(o, WIDE ? ray_inv<false>(d) : inv, F3(m1.x, m1.y, m1.z), F3(m2.x, m2.y, m2.z));
+                            ok = ray_aabb_ref(o, exact_inv<WIDE>(inv, d), F3(m1.x, m1.y, m1.z), F3(m2.x, m2.y, m2.z));
                             if (COUNT) c.meshes++;
                         }
                         if (ok) { t = dst; seq = sq; rec = first; hu = u; hv = v; }
@@ -943,11 +956,9 @@ __device__ __forceinline__ uint32_t queue_slot(unsigned long long *ctr, bool ali
 
 // One segment of one path (body of the loop at ray_tracing.wgsl:185-201): trace, then either add
 // the sky term and end (miss) or scatter and keep going (hit).  Returns true if the path goes on.
-template <bool COUNT>
-__device__ __forceinline__ bool path_segment(const RtSceneDev &S, uint32_t flags, int *stk, f3 &o, f3 &d, f3 &col,
-                                             uint32_t &rng, float4 *acc, Cnt &c) {
-    Hit h;
-    trace<false, COUNT>(S, o, d, flags, stk, h, c);
+// The traversal itself only needs the ray: colour, RNG state and pixel are fetched (or recomputed) by the callers AFTER
+// trace<> returns, so that they do not occupy registers -- and get spilled -- inside the traversal loop.
+__device__ __forceinline__ bool path_scatter(const RtSceneDev &S, const Hit &h, f3 &o, f3 &d, f3 &col, uint32_t &rng, float4 *acc) {
     if (h.hit) {
         f3 point, normal; uint32_t material;
         finish_hit(S, o, d, h, point, normal, material);
@@ -991,13 +1002,17 @@ __global__ __launch_bounds__(RT_BLOCK, RT_MIN_WAVES) void k_path_start(RtSceneDe
             pixel = py * V.width + px;
             f3 d0;
             ray_gen(V, px, py, o, d0);
-            rng = rt_seed(pixel, sample, seed, stream_id);
-            float jx = rt_rand(rng), jy = rt_rand(rng);
+            uint32_t r0 = rt_seed(pixel, sample, seed, stream_id);
+            float jx = rt_rand(r0), jy = rt_rand(r0);
             d = add(d0, scl(F3(jx, jy, 0.0f), 0.0015f));   // wgsl:184, not renormalised
-            col = F3(1.0f, 1.0f, 1.0f);
             float4 *acc = accum + pixel;
             float4 a = *acc; a.w = a.w + 1.0f; *acc = a;   // one more sample for this pixel
-            alive = path_segment<COUNT>(S, flags, stk, o, d, col, rng, acc, c) && max_segments > 1;
+            Hit h;
+            trace<false, COUNT>(S, o, d, flags, stk, h, c);
+            rng = rt_seed(pixel, sample, seed, stream_id);       // recomputed, not kept across the traversal
+            (void)rt_rand(rng); (void)rt_rand(rng);
+            col = F3(1.0f, 1.0f, 1.0f);
+            alive = path_scatter(S, h, o, d, col, rng, accum + pixel) && max_segments > 1;
             ++n_primary;
         }
         uint32_t slot = queue_slot(counters + qo_ctr, alive);
@@ -1045,9 +1060,11 @@ __global__ __launch_bounds__(RT_BLOCK, RT_MIN_WAVES) void k_path_bounce(RtSceneD
         if (active) {
             o = F3(qi.ox[i], qi.oy[i], qi.oz[i]);
             d = F3(qi.dx[i], qi.dy[i], qi.dz[i]);
-            col = F3(qi.cr[i], qi.cg[i], qi.cb[i]);
+            Hit h;
+            trace<false, COUNT>(S, o, d, flags, stk, h, c);
+            col = F3(qi.cr[i], qi.cg[i], qi.cb[i]);              // fetched after the traversal (registers)
             rng = qi.rng[i]; pixel = qi.pixel[i];
-            alive = path_segment<COUNT>(S, flags, stk, o, d, col, rng, accum + pixel, c) && !is_last;
+            alive = path_scatter(S, h, o, d, col, rng, accum + pixel) && !is_last;
             ++n_bounce;
         }
         uint32_t slot = queue_slot(counters + qo_ctr, alive);

@@ -25,7 +25,8 @@ struct TmpNode {
     uint32_t first, count;     // leaf: run in the prim array
 };
 
-constexpr int kBins = 16;
+constexpr int kMaxBins = 64;
+int kBins = 16;           // RT_TUNE_BINS (experiments)
 // SAH cost model; env overrides are experiment hooks (RT_TUNE_COST_TRI, RT_TUNE_MAX_LEAF)
 // kCostTri 2: with four children decided per node fetch a triangle test costs about two node steps; the build then
 // splits down to (mostly) single-triangle leaves: bench scene 0.87 -> 0.83 ms, 1 M-triangle soup 0.66 -> 0.64 (1 was
@@ -89,8 +90,8 @@ struct Builder {
                 float ext = chi[ax] - clo[ax];
                 if (!(ext > 0.0f)) continue;
                 float scale = (float)kBins / ext;
-                uint32_t cnt[kBins] = {0};
-                float blo[kBins][3], bhi[kBins][3];
+                uint32_t cnt[kMaxBins] = {0};
+                float blo[kMaxBins][3], bhi[kMaxBins][3];
                 for (int k = 0; k < kBins; ++k) box_reset(blo[k], bhi[k]);
                 for (size_t i = b; i < e; ++i) {
                     int k = (int)((prims[i].c[ax] - clo[ax]) * scale);
@@ -98,7 +99,7 @@ struct Builder {
                     cnt[k]++;
                     box_grow(blo[k], bhi[k], prims[i].lo, prims[i].hi);
                 }
-                float ra[kBins]; uint32_t rc[kBins];
+                float ra[kMaxBins]; uint32_t rc[kMaxBins];
                 float lo[3], hi[3];
                 box_reset(lo, hi);
                 uint32_t c = 0;
@@ -175,6 +176,7 @@ void rt_bvh_build(const rt_triangle *tris, size_t n_tris, const rt_mesh_info *me
     out->max_depth = 0; out->max_leaf = 0; out->sah_cost = 0.0; out->dropped = 0;
 
     if (const char *e = std::getenv("RT_TUNE_COST_TRI")) kCostTri = (float)std::atof(e);
+    if (const char *e = std::getenv("RT_TUNE_BINS")) { int v = std::atoi(e); if (v >= 4 && v <= kMaxBins) kBins = v; }
     if (const char *e = std::getenv("RT_TUNE_MAX_LEAF")) { int v = std::atoi(e); if (v >= 1 && v <= 8) kMaxLeaf = (uint32_t)v; }
     Builder B;
     size_t total = 0;

@@ -67,6 +67,10 @@ void rth_camera_set_graph(rth_app *app, int ray_tracing_graph);   /* Tab toggle,
 #define RTH_KEY_ASCEND 16u
 #define RTH_KEY_DESCEND 32u
 void rth_fly_cam_step(rth_app *app, float mouse_dx, float mouse_dy, uint32_t keys, float dt);
+/* The same driven from text, one step per line: "dt mouse_dx mouse_dy [keys]", keys from
+ * W A S D (src/fly_cam.rs:47-50), ^ = Space / ascend (:51), v = ShiftLeft / descend (:52), - = none; # comments.
+ * Returns the number of steps run, or -(line number) of the first malformed line. */
+long rth_fly_cam_run_script(rth_app *app, const char *text);
 /* View uniform pieces: world_from_clip[16] column-major, world_position[3] */
 void rth_camera_view(rth_app *app, float world_from_clip[16], float world_position[3]);
 
@@ -75,6 +79,12 @@ int rth_prepare_meshinfo(rth_app *app);   /* 0 ok, -1 = the reference would pani
 void rth_info_counts(rth_app *app, size_t *n_tri, size_t *n_mesh, size_t *n_vtx, size_t *n_mat);
 void rth_info_copy(rth_app *app, rt_triangle *tris, rt_mesh_info *meshes, rt_vertex *verts, rt_material *mats);
 const char *rth_log(rth_app *app);
+
+/* ---- presentation to files: the BGRA8 sRGB frame of rt_read_bgra8_srgb, i.e. what the
+ * reference's Bgra8UnormSrgb target holds (src/pipeline.rs:56-60), as binary PPM (RGB) or PNG (RGBA, sRGB chunk,
+ * stored deflate).  0 ok, -1 bad argument, -2 I/O error.  Host only. */
+int rth_write_ppm(const char *path, const uint8_t *bgra, uint32_t width, uint32_t height);
+int rth_write_png(const char *path, const uint8_t *bgra, uint32_t width, uint32_t height);
 
 /* ---- entity introspection (to feed the same entities to an independent checker) ---------------- */
 size_t rth_entity_count(rth_app *app);

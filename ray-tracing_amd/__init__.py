@@ -87,7 +87,8 @@ RTH_SYMBOLS = ["rth_app_create", "rth_app_destroy", "rth_app_finish", "rth_app_u
                "rth_spawn_default_scene", "rth_spawn_sphere_field", "rth_spawn_icosphere_soup", "rth_rotate_tagged",
                "rth_camera_look_at", "rth_camera_frame_scene", "rth_camera_frame_scene_at", "rth_camera_set_target", "rth_camera_set_projection",
                "rth_camera_set_graph", "rth_fly_cam_step", "rth_camera_view", "rth_prepare_meshinfo",
-               "rth_info_counts", "rth_info_copy", "rth_log", "rth_entity_count", "rth_entity_get"]
+               "rth_info_counts", "rth_info_copy", "rth_log", "rth_entity_count", "rth_entity_get",
+               "rth_fly_cam_run_script", "rth_write_ppm", "rth_write_png"]
 
 _lib = None
 
@@ -135,6 +136,8 @@ def lib():
         "rth_camera_frame_scene": (None, [vp]), "rth_camera_frame_scene_at": (None, [vp, C.c_float]), "rth_camera_set_target": (None, [vp, u32, u32, C.POINTER(u32)]),
         "rth_camera_set_projection": (None, [vp, C.c_float, C.c_float]), "rth_camera_set_graph": (None, [vp, i]),
         "rth_fly_cam_step": (None, [vp, C.c_float, C.c_float, u32, C.c_float]),
+        "rth_fly_cam_run_script": (C.c_long, [vp, C.c_char_p]),
+        "rth_write_ppm": (i, [C.c_char_p, vp, u32, u32]), "rth_write_png": (i, [C.c_char_p, vp, u32, u32]),
         "rth_camera_view": (None, [vp, fp, fp]), "rth_prepare_meshinfo": (i, [vp]),
         "rth_info_counts": (None, [vp, C.POINTER(sz), C.POINTER(sz), C.POINTER(sz), C.POINTER(sz)]),
         "rth_info_copy": (None, [vp, vp, vp, vp, vp]), "rth_log": (C.c_char_p, [vp]),
@@ -209,6 +212,16 @@ def analytic_sphere_field(n, seed):
         mats["color"][ground.materials.size + k] = (uniform(0.1, 1.0), uniform(0.1, 1.0), uniform(0.1, 1.0), 1.0)
     idx = np.arange(ground.materials.size, ground.materials.size + n, dtype=np.uint32)
     return Scene(ground.triangles, ground.meshes, ground.vertices, mats, spheres, idx)
+
+
+def write_image(path, bgra):
+    """The presented frame (H, W, 4 uint8 BGRA, sRGB-encoded: Context.read_bgra8_srgb) as .ppm or .png."""
+    bgra = np.ascontiguousarray(bgra, dtype=np.uint8)
+    h, w = bgra.shape[:2]
+    fn = lib().rth_write_png if str(path).lower().endswith(".png") else lib().rth_write_ppm
+    rc = fn(str(path).encode(), bgra.ctypes.data, w, h)
+    if rc != 0:
+        raise OSError(f"write_image({path}): status {rc}")
 
 
 def host_bvh_build(scene, threads=0, refit_to=None, wide=False):
@@ -470,6 +483,13 @@ class App:
 
     def fly_cam_step(self, mouse_dx=0.0, mouse_dy=0.0, keys=0, dt=0.0):
         lib().rth_fly_cam_step(self._h, mouse_dx, mouse_dy, keys, dt)
+
+    def fly_cam_run_script(self, text):
+        """One fly-cam step per line: 'dt mouse_dx mouse_dy [keys]' (rt_host.h). Returns the number of steps."""
+        n = lib().rth_fly_cam_run_script(self._h, text.encode())
+        if n < 0:
+            raise ValueError(f"fly-cam script: malformed line {-n}")
+        return n
 
     def camera_view(self):
         m, p = np.zeros(16, np.float32), np.zeros(3, np.float32)

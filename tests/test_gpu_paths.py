@@ -132,6 +132,26 @@ def test_presentation_bgra8_srgb():
     ctx.close()
 
 
+def test_presented_frame_to_png_and_ppm(tmp_path):
+    """f2: the frame as the reference's Bgra8UnormSrgb target holds it, written where a screenshot of the app can be
+    compared with it."""
+    import zlib
+    app = default_app(96, 54)
+    scene = app.prepare_meshinfo()
+    ctx, rgba, _, _ = gpu_render(app, scene, rt.FLAG_SHADOW)
+    bgra = ctx.read_bgra8_srgb()
+    rt.write_image(tmp_path / "frame.png", bgra)
+    rt.write_image(tmp_path / "frame.ppm", bgra)
+    raw = (tmp_path / "frame.ppm").read_bytes()
+    rgb = np.frombuffer(raw[raw.index(b"255\n") + 4:], np.uint8).reshape(54, 96, 3)
+    assert np.array_equal(rgb, bgra[..., [2, 1, 0]]) and rgb.max() > 100 and rgb.min() == 0
+    png = (tmp_path / "frame.png").read_bytes()
+    idat = png[png.index(b"IDAT") + 4:png.index(b"IEND") - 8]
+    rows = np.frombuffer(zlib.decompress(idat), np.uint8).reshape(54, 96 * 4 + 1)
+    assert np.array_equal(rows[:, 1:].reshape(54, 96, 4)[..., :3], rgb)
+    ctx.close()
+
+
 def test_plugin_lifecycle_and_dirty_upload():
     app = default_app(80, 45)
     assert app.update() == rt.RT_NOT_READY                         # pipeline not created yet: silent skip (src/node.rs:52-56)

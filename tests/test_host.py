@@ -176,6 +176,70 @@ def test_fly_cam_restatement():
     assert abs(np.arcsin(np.clip(m3[13], -1, 1)) - 1.54) < 1e-3
 
 
+def test_fly_cam_script_is_the_same_steps_from_text():
+    """the fly-cam driven from a scripted input file instead of window events."""
+    script = """# dt   mouse_dx mouse_dy keys
+    0.5   0      0       W          # forward for half a second
+    0.0   100    0       -          # look left
+    0.25  -30    12      WD^        # forward + right + ascend while looking around
+    0.1   0      0                  # no key column: nothing pressed
+    0.2   5      -7      sav        # lower case, backward + left + descend
+    """
+    a, b = default_app(1280, 720), default_app(1280, 720)
+    assert a.fly_cam_run_script(script) == 5
+    K = {"W": 1, "S": 2, "A": 4, "D": 8, "^": 16, "v": 32}
+    for dt, mx, my, keys in ((0.5, 0, 0, "W"), (0.0, 100, 0, ""), (0.25, -30, 12, "WD^"), (0.1, 0, 0, ""), (0.2, 5, -7, "SAv")):
+        b.fly_cam_step(mouse_dx=mx, mouse_dy=my, keys=sum(K[k] for k in keys), dt=dt)
+    ma, pa = a.camera_view()
+    mb, pb = b.camera_view()
+    assert ma.tobytes() == mb.tobytes() and pa.tobytes() == pb.tobytes()
+    m0, p0 = default_app(1280, 720).camera_view()
+    assert pa.tobytes() != p0.tobytes()
+    with pytest.raises(ValueError, match="line 2"):
+        default_app().fly_cam_run_script("0.1 0 0 W\n0.1 0 Q\n")
+    with pytest.raises(ValueError, match="line 1"):
+        default_app().fly_cam_run_script("0.1 0 0 X")
+
+
+def test_image_writers_round_trip(tmp_path):
+    """the presented BGRA8 sRGB frame as PPM and PNG; both read back to the same pixels."""
+    import struct
+    import zlib
+    rng = np.random.default_rng(1)
+    h, w = 37, 53                       # ragged sizes; > 65535 raw bytes would need two stored blocks: see below
+    bgra = rng.integers(0, 256, size=(h, w, 4), dtype=np.uint8)
+    rt.write_image(tmp_path / "f.ppm", bgra)
+    raw = (tmp_path / "f.ppm").read_bytes()
+    head = b"P6\n53 37\n255\n"
+    assert raw.startswith(head) and len(raw) == len(head) + h * w * 3
+    rgb = np.frombuffer(raw[len(head):], np.uint8).reshape(h, w, 3)
+    assert np.array_equal(rgb, bgra[..., [2, 1, 0]])
+
+    def read_png(path):
+        data = path.read_bytes()
+        assert data[:8] == b"\x89PNG\r\n\x1a\n"
+        at, chunks = 8, []
+        while at < len(data):
+            n, typ = struct.unpack(">I4s", data[at:at + 8])
+            body = data[at + 8:at + 8 + n]
+            assert zlib.crc32(typ + body) == struct.unpack(">I", data[at + 8 + n:at + 12 + n])[0]
+            chunks.append((typ, body))
+            at += 12 + n
+        assert [c[0] for c in chunks] == [b"IHDR", b"sRGB", b"IDAT", b"IEND"]
+        W, H, depth, ctype, comp, filt, inter = struct.unpack(">IIBBBBB", chunks[0][1])
+        assert (depth, ctype, comp, filt, inter) == (8, 6, 0, 0, 0)
+        rows = np.frombuffer(zlib.decompress(chunks[2][1]), np.uint8).reshape(H, W * 4 + 1)
+        assert np.all(rows[:, 0] == 0)
+        return rows[:, 1:].reshape(H, W, 4)
+    rt.write_image(tmp_path / "f.png", bgra)
+    assert np.array_equal(read_png(tmp_path / "f.png"), bgra[..., [2, 1, 0, 3]])
+    big = rng.integers(0, 256, size=(200, 300, 4), dtype=np.uint8)      # 240,200 raw bytes: four stored blocks
+    rt.write_image(tmp_path / "big.png", big)
+    assert np.array_equal(read_png(tmp_path / "big.png"), big[..., [2, 1, 0, 3]])
+    with pytest.raises(OSError):
+        rt.write_image(tmp_path / "no_such_dir" / "f.png", bgra)
+
+
 def _check_bvh(scene, nodes, recs, info):
     n_items = int(scene.meshes["tri_count"].sum())
     assert len(recs) == n_items and sorted(recs["seq"].tolist()) == list(range(n_items))

@@ -1037,10 +1037,11 @@ __global__ __launch_bounds__(RT_BLOCK, RT_MIN_WAVES) void k_path_start(RtSceneDe
 // persist != 0: one chip-full of blocks strides over the queue in 256-path chunks: later bounces hold few
 // paths, and a grid sized for the frame would spend its time dispatching empty blocks.  (Taking 64 paths at
 // a time from one work counter instead was 11 % slower on the 10 M-triangle scene.  A k_stream-style kernel
-// that refills single lanes from the queue as their segments end -- bounce rays are incoherent, a wave's node
-// steps run with 40 % of the lanes -- raised that to 51 % and was still 1.1-1.4x SLOWER: lanes that start
-// together fetch the same top-of-tree nodes in the same instruction, which the L1 front end serves as one
-// line; desynchronised lanes do not, and that front end is as busy as the VALU.  DESIGN.md section 4.)
+// that refills single lanes from the queue as their segments end -- bounce rays are incoherent, a wave's VALU
+// instructions run with 36 % of the lanes -- was 1.1-1.4x SLOWER on the binary tree and 1.2-1.8x slower on the
+// wide tree (refill thresholds 16-64, 256-path chunks per wave): lanes that start together fetch the same
+// top-of-tree nodes in the same instruction, which the L1 front end serves as one line; desynchronised lanes
+// do not.  DESIGN.md section 4.)
 template <bool COUNT>
 __global__ __launch_bounds__(RT_BLOCK, RT_MIN_WAVES) void k_path_bounce(RtSceneDev S, uint32_t flags, int is_last,
                                                           float4 *__restrict__ accum, RtPathQueue qi, RtPathQueue qo,

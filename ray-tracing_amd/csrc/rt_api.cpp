@@ -511,7 +511,7 @@ int rt_update_vertices(rt_ctx *c, const rt_vertex *verts, size_t n_verts, const 
         }
         // the wide tree's boxes are re-quantised from the refitted binary boxes (its topology does not change)
         HIPCHK(c, rtk_launch_wide_requant(c->stream, (const RtBvhNode *)c->d_nodes, (const RtWideSrc *)c->d_wide_src,
-                                          (RtWideNode *)c->d_wide, c->S.n_wide));
+                                          (RtWideNode *)c->d_wide, (uint32_t)c->wide_host.nodes.size()));
         HIPCHK(c, hipEventRecord(e1, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));   // host arrays are borrowed for this call only
         float ms = 0.0f;
@@ -519,6 +519,14 @@ int rt_update_vertices(rt_ctx *c, const rt_vertex *verts, size_t n_verts, const 
         (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
         refit_ms = ms;
         c->bvh_host_stale = true;
+    }
+    // moved vertices may have left the coordinate range the wide step is good for (rt_layout.h): then the binary tree
+    // is walked until they are back (spheres do not move; unused vertices count too, which only errs on the safe side)
+    {
+        float amax = 0.0f;
+        for (size_t i = 0; i < n_verts; ++i)
+            for (int k = 0; k < 3; ++k) { float v = std::fabs(verts[i].pos[k]); if (v > amax) amax = v; }   // NaN never raises amax
+        c->S.n_wide = amax * 1.0001f < RT_WIDE_COORD_MAX ? (uint32_t)c->wide_host.nodes.size() : 0u;
     }
     c->h_meshes.assign(meshes, meshes + n_meshes);
     c->info.build_ms = refit_ms;
@@ -763,7 +771,7 @@ int rt_read_bvh(rt_ctx *c, void *nodes, size_t node_bytes_total, void *tris, siz
 int rt_read_bvh_wide(rt_ctx *c, void *wide_nodes, size_t bytes_total) {
     if (!c) return RT_ERR_ARG;
     if (!c->has_scene) return RT_NOT_READY;
-    if (bytes_total != (size_t)c->S.n_wide * sizeof(RtWideNode))
+    if (bytes_total != c->wide_host.nodes.size() * sizeof(RtWideNode))
         return fail(c, RT_ERR_ARG, "rt_read_bvh_wide: buffer size must be n_wide_nodes * 64");
     HIPCHK(c, hipSetDevice(c->device));
     if (wide_nodes && bytes_total) HIPCHK(c, hipMemcpyAsync(wide_nodes, c->d_wide, bytes_total, hipMemcpyDeviceToHost, c->stream));

@@ -228,6 +228,21 @@ def test_update_vertices_refit_matches_a_rebuild_and_rejects_other_topologies():
         assert np.array_equal(wide_h["child"], wide_0["child"])                   # topology kept
         assert ctx.render(flags=rt.FLAG_SHADOW | rt.FLAG_BINARY_TREE) == rt.RT_OK # both trees give the oracle's frame
         assert bitwise_equal(ctx.read_prim_ids(), prim_o) and bitwise_equal(ctx.read_radiance(), rgba_o)
+        # vertices that leave the wide step's coordinate range (RT_WIDE_COORD_MAX): the same frame from the binary tree
+        far = rt.Scene(scene.triangles, moved.meshes.copy(), moved.vertices.copy(), scene.materials)
+        far.vertices["pos"][:, 0] += np.float32(1e8)
+        far.meshes["aabb_min"][:, 0] += np.float32(1e8)
+        far.meshes["aabb_max"][:, 0] += np.float32(1e8)
+        ctx.update_vertices(far)
+        assert ctx.render(flags=rt.FLAG_SHADOW | rt.FLAG_COUNTERS) == rt.RT_OK
+        v_far = ctx.counters().node_visits
+        prim_far = ctx.read_prim_ids()
+        assert ctx.render(flags=rt.FLAG_SHADOW | rt.FLAG_COUNTERS | rt.FLAG_BINARY_TREE) == rt.RT_OK
+        assert ctx.counters().node_visits == v_far and bitwise_equal(ctx.read_prim_ids(), prim_far)
+        ctx.update_vertices(moved)                                                 # ... and back in range: wide again
+        assert ctx.render(flags=rt.FLAG_SHADOW | rt.FLAG_COUNTERS) == rt.RT_OK
+        assert ctx.counters().node_visits < 0.75 * v_far * 10 and bitwise_equal(ctx.read_prim_ids(), prim_o)
+        assert bitwise_equal(ctx.read_bvh()[0], nodes_h) and ctx.bvh_info().n_refits == 3
         bad = rt.Scene(scene.triangles, moved.meshes, moved.vertices.copy(), scene.materials)
         bad.vertices["pos"][int(moved.triangles["indices"][0][0])] = np.nan       # a non-finite vertex needs a rebuild
         with pytest.raises(rt.RtError) as e:

@@ -192,22 +192,27 @@ def main():
 
     acc_t = None
     if samples:
-        _, _, d_acc = ctx.device_buffers()
+        d_rad_s, _, d_acc = ctx.device_buffers()
 
         class _PtrA:
             __cuda_array_interface__ = dict(shape=(H * W * 4,), typestr="<f4", data=(d_acc, False), version=2)
+
+        class _PtrR:
+            __cuda_array_interface__ = dict(shape=(H * W * 4,), typestr="<f4", data=(d_rad_s, False), version=2)
         acc_t = torch.as_tensor(_PtrA(), device=f"cuda:{local_rank}")
+        rad_s = torch.as_tensor(_PtrR(), device=f"cuda:{local_rank}")
+        from ray_tracing_amd import multi_gpu
+        gloo_s = dist.get_backend() == "gloo"
+        # direct reduce-scatter over the point-to-point links + gather of the resolved slices to rank 0
+        reducer = multi_gpu.SampleReduce(H * W * 4, world, rank, "cpu" if gloo_s else f"cuda:{local_rank}", gather_to=0)
 
     def step(f):
         ctx.render(flags=f, **shard)
         if samples:
-            if dist.get_backend() == "gloo":                  # rehearsal only: gloo reduces host tensors
-                host = acc_t.cpu()
-                dist.all_reduce(host, op=dist.ReduceOp.SUM)
-                acc_t.copy_(host)
-            else:
-                dist.all_reduce(acc_t, op=dist.ReduceOp.SUM)  # running sums of all ranks' sample slices
-            ctx.resolve_accumulation(spp * world)             # radiance = sum / total samples, on the device
+            # running sums of all ranks' sample slices -> radiance = sum / total samples in rank 0's radiance buffer
+            res = reducer.combine(acc_t.cpu() if gloo_s else acc_t, spp * world)   # gloo (rehearsal only) moves host tensors
+            if rank == 0:
+                rad_s.copy_(res)
         if tiles:
             # every rank sends its own tiles, packed, straight to rank 0: one xGMI link per peer, 1/N of a frame each
             if gloo:                                          # rehearsal only: gloo moves host tensors
@@ -268,7 +273,7 @@ def main():
                        "rays_per_step_rank0": int(rays_step),
                        "primary_hit_fraction": round(hits / max(cnt.rays_primary, 1), 4), "camera_radii": CAMERA_RADII,
                        "parallelism": ("tiles64-roundrobin+packed-gather-to-rank0" if tiles else
-                                       (f"sample-slices{world}+allreduce" if samples else f"frames-dp{world}"))},
+                                       (f"sample-slices{world}+direct-reduce-scatter+gather-to-rank0" if samples else f"frames-dp{world}"))},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "kernel": ("k_path_start+k_path_bounce (whole frame)" if spp else "k_stream<false, true>"),

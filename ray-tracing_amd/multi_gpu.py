@@ -10,6 +10,11 @@
             (TileGather).  xGMI is point-to-point: a ring all_reduce of the whole frame moves
             2*(N-1)/N frames over every link (1080p RGBA f32, 8 GPUs: 58 MB per link, ~0.38 ms at 153 GB/s),
             the direct gather 1/N of a frame over each of the N-1 links into rank 0 (4.1 MB, ~0.03 ms).
+  samples, direct : SampleReduce -- the same sum as a direct reduce-scatter: every rank sends slice j of its running
+            sums straight to rank j (all_to_all: N-1 sends of 1/N of the buffer, one per xGMI link, all links busy at
+            once), adds the N slices it received, and the slices are gathered.  A ring moves 2*(N-1)/N of the buffer
+            over every link one hop at a time (8K RGBA f32, 8 GPUs: 0.93 GB per link, ~6 ms); the direct form moves
+            66 MB per link per phase (~0.45 ms each).  SURVEY 8e.
 These helpers only move tensors; they work on any torch device.
 """
 import numpy as np
@@ -35,6 +40,39 @@ def combine_samples(accum, total_samples, group=None):
     import torch.distributed as dist
     dist.all_reduce(accum, op=dist.ReduceOp.SUM, group=group)
     return accum / float(total_samples)
+
+
+class SampleReduce:
+    """Direct reduce-scatter + gather of the accumulation buffers over point-to-point links (all_to_all), instead of a
+    ring all_reduce.  combine(accum, total_samples) returns the resolved radiance (sum / total_samples): on every rank
+    with gather_to=None (all_gather), else only on rank gather_to (None elsewhere).  Summation order: ranks 0..N-1 per
+    element, the same on every rank (a ring's order depends on the element's position) -- still not the order of one
+    GPU doing all samples, so the RMSE gate applies, not bits."""
+
+    def __init__(self, n_floats, world, rank, device="cpu", group=None, gather_to=None):
+        import torch
+        self.world, self.rank, self.group, self.gather_to, self.n = world, rank, group, gather_to, n_floats
+        self.slice = (n_floats + world - 1) // world                       # padded so that every slice has one size
+        self.send = torch.zeros(self.slice * world, dtype=torch.float32, device=device)
+        self.recv = torch.zeros(self.slice * world, dtype=torch.float32, device=device)
+        self.part = torch.zeros(self.slice, dtype=torch.float32, device=device)
+        self.full = torch.zeros(self.slice * world, dtype=torch.float32, device=device)
+
+    def combine(self, accum, total_samples):
+        import torch.distributed as dist
+        self.send[: self.n].copy_(accum.reshape(-1))
+        dist.all_to_all_single(self.recv, self.send, group=self.group)      # slice j of every rank -> rank j
+        parts = self.recv.view(self.world, self.slice)
+        self.part.copy_(parts[0])
+        for r in range(1, self.world):                                      # fixed order: rank 0, 1, ..., N-1
+            self.part.add_(parts[r])
+        self.part.div_(float(total_samples))
+        if self.gather_to is None:
+            dist.all_gather_into_tensor(self.full, self.part, group=self.group)
+            return self.full[: self.n]
+        out = list(self.full.view(self.world, self.slice).unbind(0)) if self.rank == self.gather_to else None
+        dist.gather(self.part, out, dst=self.gather_to, group=self.group)
+        return self.full[: self.n] if self.rank == self.gather_to else None
 
 
 def wrap_device_buffer(ptr, n_floats, device_index):

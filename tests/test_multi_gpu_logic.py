@@ -60,6 +60,21 @@ def _worker(rank, world, port, out):
     ref_acc, _ = orc.render_path(s, v, 2 * world, 4, seed=3, threads=1)
     ref = orc.resolve(ref_acc, 2 * world)
     rmse = float(np.sqrt(np.mean((res.astype(np.float64) - ref.astype(np.float64)) ** 2)))
+    # the same sum as a direct reduce-scatter + gather (point-to-point sends instead of a ring)
+    flat = torch.from_numpy(acc.copy()).reshape(-1)
+    sr = multi_gpu.SampleReduce(flat.numel(), world, rank)
+    res2 = sr.combine(flat, 2 * world).numpy().reshape(res.shape)
+    sr0 = multi_gpu.SampleReduce(flat.numel(), world, rank, gather_to=0)
+    res3 = sr0.combine(flat, 2 * world)
+    rmse2 = float(np.sqrt(np.mean((res2.astype(np.float64) - ref.astype(np.float64)) ** 2)))
+    direct_ok = rmse2 <= 1e-3 and np.allclose(res2, res, rtol=1e-6, atol=1e-7)
+    if rank == 0:
+        direct_ok = direct_ok and res3 is not None and res3.numpy().tobytes() == res2.reshape(-1).tobytes()
+    else:
+        direct_ok = direct_ok and res3 is None
+    ok_t = torch.tensor([1.0 if direct_ok else 0.0])
+    dist.all_reduce(ok_t, op=dist.ReduceOp.MIN)
+    rmse = max(rmse, 0.0 if ok_t.item() == 1.0 else 1.0)
     if rank == 0:
         np.save(out, np.array([float(tiles_ok), rmse, float(np.abs(owner - np.roll(owner, 16, axis=1)).max())]))
     dist.destroy_process_group()

@@ -789,30 +789,15 @@ __global__ __launch_bounds__(RT_BLOCK, RT_MIN_WAVES) void k_stream(
                     q4 q2 = {sp_[8], sp_[9], sp_[10], sp_[11]}, q3 = {sp_[12], sp_[13], sp_[14], sp_[15]};
                     if (cur >= 0) {
                         if (COUNT) { c.nodes++; if (lane == (uint32_t)__builtin_ctzll(m_node)) { c.wnodes++; c.walive += n_node + n_leaf; } }
-#ifdef RT_TRIP_LIMIT
-                        const int cur_was = cur;
-#endif
                         if (WIDE) wide_decide(q0, q1, q2, q3, o, inv, t, cur, sp, stk, ovf);
                         else node_decide(q0, q1, q2, q3, o, inv, t, cur, sp, stk, ovf);
-#ifdef RT_TRIP_LIMIT
-                        if (idx == RT_DBG_PIXEL && state == 1) printf("S node %d -> %d sp %d t %g\n", cur_was, cur, sp, t);
-#endif
                     }
                 } else if (cur >= 0) {
                     const float4 *p = reinterpret_cast<const float4 *>(nodes + cur);
                     float4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3];
                     if (COUNT) { c.nodes++; if (lane == (uint32_t)__builtin_ctzll(m_node)) { c.wnodes++; c.walive += n_node + n_leaf; } }
-#ifdef RT_TRIP_LIMIT
-                    const int cur_was = cur;
-#endif
                     if (WIDE) wide_decide(q0, q1, q2, q3, o, inv, t, cur, sp, stk, ovf);
                     else node_decide(q0, q1, q2, q3, o, inv, t, cur, sp, stk, ovf);
-#ifdef RT_TRIP_LIMIT
-                    if (idx == RT_DBG_PIXEL && state == 1)
-                        printf("V node %d -> %d sp %d t %g | org %g %g %g scl %g %g %g lo %08x %08x %08x hi %08x %08x %08x ch %d %d %d %d | o %g %g %g inv %g %g %g\n", cur_was, cur, sp, t,
-                               q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, __float_as_uint(q1.z), __float_as_uint(q1.w), __float_as_uint(q2.x), __float_as_uint(q2.y), __float_as_uint(q2.z), __float_as_uint(q2.w),
-                               __float_as_int(q3.x), __float_as_int(q3.y), __float_as_int(q3.z), __float_as_int(q3.w), o.x, o.y, o.z, inv.x, inv.y, inv.z);
-#endif
                 }
             } else {
                 if (cur < 0 && cur != RT_DONE) {

@@ -87,6 +87,15 @@ int rt_upload_scene_ex(rt_ctx *ctx,
  * instead of rebuilt.  Returns RT_ERR_SCENE if the topology differs (call rt_upload_scene instead). */
 int rt_update_vertices(rt_ctx *ctx, const rt_vertex *vertices, size_t n_vertices,
                        const rt_mesh_info *meshes, size_t n_meshes);
+/* The dirty-mesh form of the same ("re-bake only moved meshes"): only meshes
+ * [first_mesh, first_mesh + n_meshes) moved.  `meshes` holds their n_meshes new T2 entries, `vertices` the
+ * n_vertices new T3 entries that replace [first_vertex, first_vertex + n_vertices) -- a range that must cover
+ * every vertex those meshes' triangles use and none that a triangle of another mesh uses.  Only these bytes
+ * cross PCIe; on the device only the leaves of those meshes are re-baked and only their ancestors refitted
+ * (and re-quantised), the result being the tree rt_update_vertices would leave, bit for bit.
+ * No reference counterpart (the reference has no incremental path at all). */
+int rt_update_vertex_range(rt_ctx *ctx, const rt_vertex *vertices, size_t first_vertex, size_t n_vertices,
+                           const rt_mesh_info *meshes, size_t first_mesh, size_t n_meshes);
 
 /* ---- view: replaces bind group 0 (View uniform, dynamic offset) and
  * set_camera_viewport (src/node.rs:58-62,71-76; ray_tracing.wgsl:5,176-177).

@@ -79,6 +79,9 @@ int rth_prepare_meshinfo(rth_app *app);   /* 0 ok, -1 = the reference would pani
 void rth_info_counts(rth_app *app, size_t *n_tri, size_t *n_mesh, size_t *n_vtx, size_t *n_mat);
 void rth_info_copy(rth_app *app, rt_triangle *tris, rt_mesh_info *meshes, rt_vertex *verts, rt_material *mats);
 const char *rth_log(rth_app *app);
+/* How RayTracingPassNode::run applied vertex-only changes so far: rt_update_vertex_range (one run of moved meshes,
+ * SURVEY 8f item 1) or rt_update_vertices (everything). */
+void rth_update_counts(rth_app *app, uint32_t *range_updates, uint32_t *full_updates);
 
 /* ---- presentation to files: the BGRA8 sRGB frame of rt_read_bgra8_srgb, i.e. what the
  * reference's Bgra8UnormSrgb target holds (src/pipeline.rs:56-60), as binary PPM (RGB) or PNG (RGBA, sRGB chunk,

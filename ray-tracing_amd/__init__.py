@@ -77,7 +77,7 @@ class EntityView(C.Structure):
 
 
 # every symbol include/rt_amd.h and include/rt_host.h declare
-RT_SYMBOLS = ["rt_create", "rt_destroy", "rt_set_stream", "rt_upload_scene", "rt_upload_scene_ex", "rt_update_vertices", "rt_host_bvh_refit", "rt_set_view", "rt_render",
+RT_SYMBOLS = ["rt_create", "rt_destroy", "rt_set_stream", "rt_upload_scene", "rt_upload_scene_ex", "rt_update_vertices", "rt_update_vertex_range", "rt_host_bvh_refit", "rt_set_view", "rt_render",
               "rt_synchronize", "rt_read_radiance", "rt_read_prim_ids", "rt_read_hit_t", "rt_read_bgra8_srgb",
               "rt_read_accumulation", "rt_device_buffers", "rt_resolve_accumulation", "rt_get_counters",
               "rt_get_bvh_info", "rt_read_bvh", "rt_read_bvh_wide", "rt_host_bvh_build", "rt_host_bvh_copy", "rt_host_bvh_wide", "rt_host_bvh_free", "rt_last_error", "rt_status_string", "rt_version"]
@@ -88,7 +88,7 @@ RTH_SYMBOLS = ["rth_app_create", "rth_app_destroy", "rth_app_finish", "rth_app_u
                "rth_camera_look_at", "rth_camera_frame_scene", "rth_camera_frame_scene_at", "rth_camera_set_target", "rth_camera_set_projection",
                "rth_camera_set_graph", "rth_fly_cam_step", "rth_camera_view", "rth_prepare_meshinfo",
                "rth_info_counts", "rth_info_copy", "rth_log", "rth_entity_count", "rth_entity_get",
-               "rth_fly_cam_run_script", "rth_write_ppm", "rth_write_png"]
+               "rth_fly_cam_run_script", "rth_write_ppm", "rth_write_png", "rth_update_counts"]
 
 _lib = None
 
@@ -108,6 +108,7 @@ def lib():
         "rt_upload_scene": (i, [vp, vp, sz, vp, sz, vp, sz, vp, sz]),
         "rt_upload_scene_ex": (i, [vp, vp, sz, vp, sz, vp, sz, vp, sz, vp, vp, sz]),
         "rt_update_vertices": (i, [vp, vp, sz, vp, sz]),
+        "rt_update_vertex_range": (i, [vp, vp, sz, sz, vp, sz, sz]),
         "rt_host_bvh_refit": (i, [vp, vp, sz, vp, sz, i]),
         "rt_set_view": (i, [vp, fp, fp, u32, u32, C.POINTER(u32)]),
         "rt_render": (i, [vp, C.POINTER(RenderParams)]), "rt_synchronize": (i, [vp]),
@@ -137,6 +138,7 @@ def lib():
         "rth_camera_set_projection": (None, [vp, C.c_float, C.c_float]), "rth_camera_set_graph": (None, [vp, i]),
         "rth_fly_cam_step": (None, [vp, C.c_float, C.c_float, u32, C.c_float]),
         "rth_fly_cam_run_script": (C.c_long, [vp, C.c_char_p]),
+        "rth_update_counts": (None, [vp, C.POINTER(u32), C.POINTER(u32)]),
         "rth_write_ppm": (i, [C.c_char_p, vp, u32, u32]), "rth_write_png": (i, [C.c_char_p, vp, u32, u32]),
         "rth_camera_view": (None, [vp, fp, fp]), "rth_prepare_meshinfo": (i, [vp]),
         "rth_info_counts": (None, [vp, C.POINTER(sz), C.POINTER(sz), C.POINTER(sz), C.POINTER(sz)]),
@@ -303,6 +305,12 @@ class Context:
     def update_vertices(self, scene):
         v, m = scene.vertices, scene.meshes
         return self._chk(lib().rt_update_vertices(self._h, v.ctypes.data, v.size, m.ctypes.data, m.size))
+
+    def update_vertex_range(self, scene, first_vertex, n_vertices, first_mesh, n_meshes):
+        """Only meshes [first_mesh, first_mesh + n_meshes) of `scene` moved; their vertices are [first_vertex, +n_vertices)."""
+        v = np.ascontiguousarray(scene.vertices[first_vertex:first_vertex + n_vertices])
+        m = np.ascontiguousarray(scene.meshes[first_mesh:first_mesh + n_meshes])
+        return self._chk(lib().rt_update_vertex_range(self._h, v.ctypes.data, first_vertex, v.size, m.ctypes.data, first_mesh, m.size))
 
     def set_view(self, world_from_clip, world_position, width, height, viewport=None):
         m, p = _f32(world_from_clip, 16), _f32(world_position, 3)
@@ -483,6 +491,12 @@ class App:
 
     def fly_cam_step(self, mouse_dx=0.0, mouse_dy=0.0, keys=0, dt=0.0):
         lib().rth_fly_cam_step(self._h, mouse_dx, mouse_dy, keys, dt)
+
+    def update_counts(self):
+        """(ranged, full) vertex-only updates RayTracingPassNode::run has made."""
+        a, b = C.c_uint32(), C.c_uint32()
+        lib().rth_update_counts(self._h, C.byref(a), C.byref(b))
+        return a.value, b.value
 
     def fly_cam_run_script(self, text):
         """One fly-cam step per line: 'dt mouse_dx mouse_dy [keys]' (rt_host.h). Returns the number of steps."""

@@ -3,6 +3,7 @@
 // There is NO CPU fallback: without a gfx950 device rt_create fails with RT_ERR_NO_GPU.
 #include <hip/hip_runtime_api.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -40,6 +41,8 @@ struct rt_ctx {
     bool bvh_host_stale = false;          // the device tree has been refitted since
     std::vector<rt_triangle> h_tris;      // topology of the uploaded scene
     std::vector<rt_mesh_info> h_meshes;
+    std::vector<uint32_t> h_mesh_vlo, h_mesh_vhi;   // per mesh: lowest / highest vertex index its triangles use
+    void *d_dirty = nullptr;              // one byte per binary node (rt_update_vertex_range)
     void *d_level_nodes = nullptr;        // node indices grouped by tree level, deepest level first (GPU refit)
     std::vector<uint32_t> level_count;    // nodes per group, in that order
 
@@ -95,7 +98,7 @@ void free_scene(rt_ctx *c) {
     free_dev(c->d_nodes); free_dev(c->d_recs); free_dev(c->d_tris);
     free_dev(c->d_meshes); free_dev(c->d_verts); free_dev(c->d_mats);
     free_dev(c->d_spheres); free_dev(c->d_sphere_mats); free_dev(c->d_level_nodes);
-    free_dev(c->d_wide); free_dev(c->d_wide_src);
+    free_dev(c->d_wide); free_dev(c->d_wide_src); free_dev(c->d_dirty);
     c->level_count.clear();
     c->has_scene = false;
     std::memset(&c->S, 0, sizeof c->S);
@@ -450,6 +453,13 @@ int rt_upload_scene_ex(rt_ctx *c, const rt_triangle *tris, size_t n_tris, const 
     c->info.wide_max_depth = c->wide_host.max_depth; c->info.wide_stack_need = c->wide_host.stack_need;
     c->h_tris.assign(tris, tris + n_tris);
     c->h_meshes.assign(meshes, meshes + n_meshes);
+    c->h_mesh_vlo.assign(n_meshes, 0xFFFFFFFFu); c->h_mesh_vhi.assign(n_meshes, 0u);
+    for (size_t m = 0; m < n_meshes; ++m)
+        for (uint32_t t = meshes[m].first_tri; t < meshes[m].first_tri + meshes[m].tri_count; ++t)
+            for (int k = 0; k < 3; ++k) {
+                c->h_mesh_vlo[m] = std::min(c->h_mesh_vlo[m], tris[t].indices[k]);
+                c->h_mesh_vhi[m] = std::max(c->h_mesh_vhi[m], tris[t].indices[k]);
+            }
     c->bvh_host = std::move(bvh);
     c->bvh_host_stale = false;
     c->has_scene = true;
@@ -532,6 +542,70 @@ int rt_update_vertices(rt_ctx *c, const rt_vertex *verts, size_t n_verts, const 
     c->info.build_ms = refit_ms;
     c->info.n_refits += 1;
     c->accum_dirty = true;                        // geometry moved: accumulation restarts
+    return RT_OK;
+}
+
+int rt_update_vertex_range(rt_ctx *c, const rt_vertex *verts, size_t first_vertex, size_t n_verts,
+                           const rt_mesh_info *meshes, size_t first_mesh, size_t n_meshes) {
+    if (!c) return RT_ERR_ARG;
+    if (!c->has_scene) return RT_NOT_READY;
+    if ((n_verts && !verts) || (n_meshes && !meshes)) return fail(c, RT_ERR_ARG, "rt_update_vertex_range: NULL array");
+    if (first_vertex + n_verts > c->S.n_verts || first_vertex + n_verts < first_vertex)
+        return fail(c, RT_ERR_SCENE, "rt_update_vertex_range: vertex range outside the uploaded scene");
+    if (first_mesh + n_meshes > c->h_meshes.size() || first_mesh + n_meshes < first_mesh)
+        return fail(c, RT_ERR_SCENE, "rt_update_vertex_range: mesh range outside the uploaded scene");
+    for (size_t m = 0; m < n_meshes; ++m)
+        if (meshes[m].first_tri != c->h_meshes[first_mesh + m].first_tri || meshes[m].tri_count != c->h_meshes[first_mesh + m].tri_count)
+            return fail(c, RT_ERR_SCENE, "rt_update_vertex_range: mesh triangle ranges differ from the uploaded scene");
+    if (c->bvh_host.dropped)
+        return fail(c, RT_ERR_SCENE, "rt_update_vertex_range: the built tree dropped non-finite triangles, rebuild with rt_upload_scene");
+    // the vertex range must hold every vertex the moved meshes use and none that another mesh uses (a leaf that is not
+    // re-baked would keep stale values): checked on the per-mesh vertex index spans recorded at upload
+    for (size_t m = 0; m < c->h_meshes.size(); ++m) {
+        if (c->h_meshes[m].tri_count == 0) continue;
+        const bool moved = m >= first_mesh && m < first_mesh + n_meshes;
+        const size_t lo = c->h_mesh_vlo[m], hi = c->h_mesh_vhi[m];      // inclusive span
+        if (moved && (lo < first_vertex || hi >= first_vertex + n_verts))
+            return fail(c, RT_ERR_SCENE, "rt_update_vertex_range: a moved mesh uses a vertex outside the range");
+        if (!moved && n_verts && hi >= first_vertex && lo < first_vertex + n_verts)
+            return fail(c, RT_ERR_SCENE, "rt_update_vertex_range: the range overlaps the vertices of a mesh that is not listed as moved");
+    }
+    float amax = 0.0f;
+    for (size_t i = 0; i < n_verts; ++i)
+        for (int k = 0; k < 3; ++k) {
+            if (!std::isfinite(verts[i].pos[k])) return fail(c, RT_ERR_SCENE, "rt_update_vertex_range: non-finite vertex, rebuild with rt_upload_scene");
+            amax = std::fmax(amax, std::fabs(verts[i].pos[k]));
+        }
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t nn = c->S.n_nodes;
+    if (!c->d_dirty && nn) HIPCHK(c, hipMalloc(&c->d_dirty, nn));
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    HIPCHK(c, hipEventCreate(&e0)); HIPCHK(c, hipEventCreate(&e1));
+    if (n_verts) HIPCHK(c, hipMemcpyAsync((rt_vertex *)c->d_verts + first_vertex, verts, n_verts * sizeof(rt_vertex), hipMemcpyHostToDevice, c->stream));
+    if (n_meshes) HIPCHK(c, hipMemcpyAsync((rt_mesh_info *)c->d_meshes + first_mesh, meshes, n_meshes * sizeof(rt_mesh_info), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipEventRecord(e0, c->stream));
+    if (nn) HIPCHK(c, hipMemsetAsync(c->d_dirty, 0, nn, c->stream));
+    size_t off = 0;
+    for (uint32_t cnt : c->level_count) {
+        HIPCHK(c, rtk_launch_refit_level_dirty(c->stream, (RtBvhNode *)c->d_nodes, (RtTriRecord *)c->d_recs, (const rt_triangle *)c->d_tris,
+                                               (const rt_vertex *)c->d_verts, (const uint32_t *)c->d_level_nodes + off, cnt,
+                                               (uint32_t)first_mesh, (uint32_t)(first_mesh + n_meshes), (uint8_t *)c->d_dirty));
+        off += cnt;
+    }
+    HIPCHK(c, rtk_launch_wide_requant_dirty(c->stream, (const RtBvhNode *)c->d_nodes, (const RtWideSrc *)c->d_wide_src,
+                                            (RtWideNode *)c->d_wide, (uint32_t)c->wide_host.nodes.size(), (const uint8_t *)c->d_dirty));
+    HIPCHK(c, hipEventRecord(e1, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));   // host arrays are borrowed for this call only
+    float ms = 0.0f;
+    HIPCHK(c, hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    c->bvh_host_stale = true;
+    // out of the wide step's coordinate range: binary tree until a full update or upload shows everything is back in
+    if (!(amax * 1.0001f < RT_WIDE_COORD_MAX)) c->S.n_wide = 0;
+    for (size_t m = 0; m < n_meshes; ++m) c->h_meshes[first_mesh + m] = meshes[m];
+    c->info.build_ms = ms;
+    c->info.n_refits += 1;
+    c->accum_dirty = true;
     return RT_OK;
 }
 

@@ -42,6 +42,15 @@ hipError_t rtk_launch_path_bounce(hipStream_t st, const RtSceneDev &S, uint32_t 
 hipError_t rtk_launch_refit_level(hipStream_t st, RtBvhNode *nodes, RtTriRecord *recs, const rt_triangle *tris,
                                   const rt_vertex *verts, const uint32_t *level_nodes, uint32_t n);
 
+// The same for a dirty range of meshes [mesh_lo, mesh_hi): a leaf is re-baked only if one of its records belongs to
+// such a mesh, an inner child re-read only if it was marked dirty by the level below; dirty[node] (one byte per binary
+// node, zeroed by the caller before the deepest level) is what the next level and the re-quantisation look at.
+hipError_t rtk_launch_refit_level_dirty(hipStream_t st, RtBvhNode *nodes, RtTriRecord *recs, const rt_triangle *tris,
+                                        const rt_vertex *verts, const uint32_t *level_nodes, uint32_t n,
+                                        uint32_t mesh_lo, uint32_t mesh_hi, uint8_t *dirty);
+hipError_t rtk_launch_wide_requant_dirty(hipStream_t st, const RtBvhNode *nodes, const RtWideSrc *src, RtWideNode *wide,
+                                         uint32_t n, const uint8_t *dirty);
+
 // after a refit: every wide node's child boxes re-quantised from the binary tree's boxes (rt_wide.h)
 hipError_t rtk_launch_wide_requant(hipStream_t st, const RtBvhNode *nodes, const RtWideSrc *src, RtWideNode *wide, uint32_t n);
 

@@ -1129,6 +1129,41 @@ __global__ void k_refit_level(RtBvhNode *nodes, RtTriRecord *recs, const rt_tria
         for (int k = 0; k < 3; ++k) { N.lo1[k] = lo[k]; N.hi1[k] = hi[k]; }
     }
 }
+// Dirty-range refit (rt_update_vertex_range): the same boxes, computed only where something below moved.
+__global__ void k_refit_level_dirty(RtBvhNode *nodes, RtTriRecord *recs, const rt_triangle *__restrict__ tris,
+                                    const rt_vertex *__restrict__ verts, const uint32_t *__restrict__ level_nodes, uint32_t n,
+                                    uint32_t mesh_lo, uint32_t mesh_hi, uint8_t *dirty) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t ni = level_nodes[i];
+    RtBvhNode &N = nodes[ni];
+    bool any = false;
+    float lo[3], hi[3];
+    for (int side = 0; side < 2; ++side) {
+        const int32_t code = side ? N.child1 : N.child0;
+        if (code == RT_CHILD_NONE) continue;
+        bool moved;
+        if (code >= 0) moved = dirty[code] != 0;
+        else {
+            uint32_t v = (uint32_t)(~code), first = v >> 3, cnt = (v & 7u) + 1u;
+            moved = false;
+            for (uint32_t k = first; k < first + cnt; ++k) { uint32_t m = recs[k].mesh; moved = moved || (m >= mesh_lo && m < mesh_hi); }
+        }
+        if (!moved) continue;
+        box_of_child(code, nodes, recs, tris, verts, lo, hi);
+        float *dl = side ? N.lo1 : N.lo0, *dh = side ? N.hi1 : N.hi0;
+        for (int k = 0; k < 3; ++k) { dl[k] = lo[k]; dh[k] = hi[k]; }
+        any = true;
+    }
+    dirty[ni] = any ? 1 : 0;
+}
+hipError_t rtk_launch_refit_level_dirty(hipStream_t st, RtBvhNode *nodes, RtTriRecord *recs, const rt_triangle *tris,
+                                        const rt_vertex *verts, const uint32_t *level_nodes, uint32_t n,
+                                        uint32_t mesh_lo, uint32_t mesh_hi, uint8_t *dirty) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_refit_level_dirty, dim3((n + 255) / 256), dim3(256), 0, st, nodes, recs, tris, verts, level_nodes, n, mesh_lo, mesh_hi, dirty);
+    return hipGetLastError();
+}
 hipError_t rtk_launch_refit_level(hipStream_t st, RtBvhNode *nodes, RtTriRecord *recs, const rt_triangle *tris,
                                   const rt_vertex *verts, const uint32_t *level_nodes, uint32_t n) {
     if (n == 0) return hipSuccess;
@@ -1142,6 +1177,24 @@ __global__ void k_wide_requant(const RtBvhNode *__restrict__ nodes, const RtWide
     RtWideNode W = wide[i];
     rt_wide_quantise(nodes, src[i], W);
     wide[i] = W;
+}
+__global__ void k_wide_requant_dirty(const RtBvhNode *__restrict__ nodes, const RtWideSrc *__restrict__ src, RtWideNode *wide, uint32_t n,
+                                     const uint8_t *__restrict__ dirty) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const RtWideSrc S = src[i];
+    bool any = false;       // a slot's box lives in binary node slot >> 1, which is dirty iff one of its two boxes changed
+    for (int k = 0; k < 4; ++k) any = any || (S.slot[k] != RT_WIDE_EMPTY && dirty[S.slot[k] >> 1] != 0);
+    if (!any) return;
+    RtWideNode W = wide[i];
+    rt_wide_quantise(nodes, S, W);
+    wide[i] = W;
+}
+hipError_t rtk_launch_wide_requant_dirty(hipStream_t st, const RtBvhNode *nodes, const RtWideSrc *src, RtWideNode *wide, uint32_t n,
+                                         const uint8_t *dirty) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_wide_requant_dirty, dim3((n + 255) / 256), dim3(256), 0, st, nodes, src, wide, n, dirty);
+    return hipGetLastError();
 }
 hipError_t rtk_launch_wide_requant(hipStream_t st, const RtBvhNode *nodes, const RtWideSrc *src, RtWideNode *wide, uint32_t n) {
     if (n == 0) return hipSuccess;

@@ -219,6 +219,10 @@ void rth_info_copy(rth_app *a, rt_triangle *t, rt_mesh_info *m, rt_vertex *v, rt
     if (c && !i.materials.empty()) std::memcpy(c, i.materials.data(), i.materials.size() * sizeof(rt_material));
 }
 const char *rth_log(rth_app *a) { return a ? a->app.world.log.c_str() : ""; }
+void rth_update_counts(rth_app *a, uint32_t *range_updates, uint32_t *full_updates) {
+    if (range_updates) *range_updates = a ? a->app.node.range_updates : 0;
+    if (full_updates) *full_updates = a ? a->app.node.full_updates : 0;
+}
 
 size_t rth_entity_count(rth_app *a) { return a ? a->app.world.entities.size() : 0; }
 int rth_entity_get(rth_app *a, size_t i, rth_entity_view *o) {

@@ -434,10 +434,40 @@ int RayTracingPassNode::run(const View &view, World &world, RayTracingPipeline &
     if (sig != uploaded_signature && topo == topology_signature && uploaded_signature != 0) {
         // only vertices / mesh boxes moved (main.rs rotates the cube every frame,
         // src/main.rs:122-126): re-bake records and refit the BVH instead of rebuilding it
-        int rc = rt_update_vertices(pipeline.ctx, info.vertices.data(), info.vertices.size(), info.meshes.data(),
-                                    info.meshes.size());
-        if (rc == RT_OK) uploaded_signature = sig;
-        else if (rc != RT_ERR_SCENE) return rc;
+        int rc = RT_ERR_SCENE;
+        // dirty-mesh form first: the meshes whose T2 entry or vertices changed, if they are one run of mesh indices
+        // with one run of vertices (an entity that moves, like main.rs's cube); the library checks the ranges
+        const size_t nv = info.vertices.size(), nm = info.meshes.size();
+        if (uploaded_vertices.size() == nv && uploaded_meshes.size() == nm && mesh_vlo.size() == nm && nv && nm) {
+            size_t lo = 0, hi = nv;
+            while (lo < nv && std::memcmp(&info.vertices[lo], &uploaded_vertices[lo], sizeof(Vertex)) == 0) ++lo;
+            while (hi > lo && std::memcmp(&info.vertices[hi - 1], &uploaded_vertices[hi - 1], sizeof(Vertex)) == 0) --hi;
+            size_t m0 = nm, m1 = 0;
+            for (size_t m = 0; m < nm; ++m) {
+                bool dirty = std::memcmp(&info.meshes[m], &uploaded_meshes[m], sizeof(MeshInfo)) != 0;
+                if (!dirty && hi > lo && info.meshes[m].tri_count) dirty = mesh_vhi[m] >= lo && mesh_vlo[m] < hi;
+                if (dirty) { m0 = std::min(m0, m); m1 = std::max(m1, m + 1); }
+            }
+            if (m0 < m1 && (m1 - m0) * 2 <= nm) {          // a small part of the scene: worth the ranged path
+                size_t v0 = nv, v1 = 0;
+                for (size_t m = m0; m < m1; ++m)
+                    if (info.meshes[m].tri_count) { v0 = std::min<size_t>(v0, mesh_vlo[m]); v1 = std::max<size_t>(v1, (size_t)mesh_vhi[m] + 1); }
+                if (v0 < v1 && v0 <= lo && hi <= v1) {
+                    rc = rt_update_vertex_range(pipeline.ctx, info.vertices.data() + v0, v0, v1 - v0, info.meshes.data() + m0, m0, m1 - m0);
+                    if (rc == RT_OK) ++range_updates;
+                    else if (rc != RT_ERR_SCENE) return rc;
+                }
+            }
+        }
+        if (rc != RT_OK) {
+            rc = rt_update_vertices(pipeline.ctx, info.vertices.data(), info.vertices.size(), info.meshes.data(), info.meshes.size());
+            if (rc == RT_OK) ++full_updates;
+        }
+        if (rc == RT_OK) {
+            uploaded_signature = sig;
+            uploaded_vertices = info.vertices;
+            uploaded_meshes = info.meshes;
+        } else if (rc != RT_ERR_SCENE) return rc;
     }
     if (sig != uploaded_signature) {
         int rc = rt_upload_scene(pipeline.ctx, info.triangles.data(), info.triangles.size(), info.meshes.data(),
@@ -446,6 +476,16 @@ int RayTracingPassNode::run(const View &view, World &world, RayTracingPipeline &
         if (rc != RT_OK) return rc;
         uploaded_signature = sig;
         topology_signature = topo;
+        uploaded_vertices = info.vertices;
+        uploaded_meshes = info.meshes;
+        mesh_vlo.assign(info.meshes.size(), 0xFFFFFFFFu);
+        mesh_vhi.assign(info.meshes.size(), 0u);
+        for (size_t m = 0; m < info.meshes.size(); ++m)
+            for (uint32_t t = info.meshes[m].first_tri; t < info.meshes[m].first_tri + info.meshes[m].tri_count; ++t)
+                for (int k = 0; k < 3; ++k) {
+                    mesh_vlo[m] = std::min(mesh_vlo[m], info.triangles[t].indices[k]);
+                    mesh_vhi[m] = std::max(mesh_vhi[m], info.triangles[t].indices[k]);
+                }
     }
     uint32_t vp[4] = {view.viewport.x, view.viewport.y, view.viewport.w, view.viewport.h};
     int rc = rt_set_view(pipeline.ctx, view.world_from_clip, view.world_position, view.width, view.height,

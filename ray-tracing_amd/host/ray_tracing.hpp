@@ -119,6 +119,11 @@ struct RayTracingPipeline {
 struct RayTracingPassNode {
     uint64_t uploaded_signature = 0;   // scene re-upload only when the arrays change
     uint64_t topology_signature = 0;   // triangles + mesh ranges + materials: unchanged => refit instead of rebuild
+    // what the device holds, to find the meshes that moved since (dirty-mesh update, rt_update_vertex_range)
+    std::vector<Vertex> uploaded_vertices;
+    std::vector<MeshInfo> uploaded_meshes;
+    std::vector<uint32_t> mesh_vlo, mesh_vhi;   // per mesh: span of vertex indices its triangles use
+    uint32_t range_updates = 0, full_updates = 0;   // how the vertex-only changes were applied (for tests)
     // Returns RT_OK, or RT_NOT_READY when the pipeline is not ready (silent skip, :52-56).
     int run(const View &view, World &world, RayTracingPipeline &pipeline, const rt_render_params *params);
 };

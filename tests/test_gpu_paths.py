@@ -170,6 +170,7 @@ def test_plugin_lifecycle_and_dirty_upload():
         rgba_o2, prim_o2, _, _ = orc.render_primary(oracle_scene(scene2), oracle_view(app), orc.FLAG_SHADOW)
         assert bitwise_equal(ctx.read_radiance(), rgba_o2) and bitwise_equal(ctx.read_prim_ids(), prim_o2)
         assert (ctx.bvh_info().n_builds, ctx.bvh_info().n_refits) == (1, frame)
+    assert app.update_counts() == (3, 0)                           # one entity of six moved: the dirty-mesh path each time
     assert app.update(flags=rt.FLAG_SHADOW) == rt.RT_OK            # nothing moved: neither upload nor refit
     assert (ctx.bvh_info().n_builds, ctx.bvh_info().n_refits) == (1, 3)
     m = app.add_material((0.1, 0.9, 0.1, 1.0))
@@ -353,6 +354,63 @@ def test_wide_tree_conservative_culling_at_the_extremes(case):
             assert ctx.counters().node_visits > visits_wide
         assert bitwise_equal(prim_g, prim_o) and bitwise_equal(t_g, t_o) and bitwise_equal(rgba_g, rgba_o)
         ctx.close()
+
+
+def test_update_vertex_range_refits_only_the_moved_meshes():
+    """f1, dirty-mesh form: four of thirty spheres move; only their vertices are sent, only their leaves re-baked and only
+    their ancestors refitted -- and the tree (binary and wide) is the one a full rt_update_vertices leaves, bit for bit."""
+    app = soup_app(30, 0x5EED0003, 160, 90, subdivisions=3)
+    app.camera_frame_scene(1.0)
+    scene = app.prepare_meshinfo()
+    m0, m1 = 5, 9
+    moved = rt.Scene(scene.triangles, scene.meshes.copy(), scene.vertices.copy(), scene.materials)
+    rng = np.random.default_rng(11)
+    v_lo, v_hi = 2**32, 0
+    for k in range(m0, m1):
+        mi = moved.meshes[k]
+        vs = np.unique(moved.triangles["indices"][mi["first_tri"]:mi["first_tri"] + mi["tri_count"]])
+        shift = rng.uniform(-4, 4, 3).astype(np.float32)
+        moved.vertices["pos"][vs] += shift
+        moved.meshes["aabb_min"][k] += shift
+        moved.meshes["aabb_max"][k] += shift
+        v_lo, v_hi = min(v_lo, int(vs.min())), max(v_hi, int(vs.max()))
+    m, p = app.camera_view()
+    rgba_o, prim_o, t_o, _ = orc.render_primary(oracle_scene(moved), oracle_view(app), orc.FLAG_SHADOW)
+    with rt.Context(0) as full, rt.Context(0) as part:
+        for ctx in (full, part):
+            ctx.upload_scene(scene)
+            ctx.set_view(m, p, 160, 90)
+        full.update_vertices(moved)
+        part.update_vertex_range(moved, v_lo, v_hi - v_lo + 1, m0, m1 - m0)
+        assert part.bvh_info().n_refits == 1
+        for tree in (0, rt.FLAG_BINARY_TREE):
+            assert part.render(flags=rt.FLAG_SHADOW | tree) == rt.RT_OK
+            assert bitwise_equal(part.read_prim_ids(), prim_o) and bitwise_equal(part.read_hit_t(), t_o)
+            assert bitwise_equal(part.read_radiance(), rgba_o)
+        nodes_f, recs_f = full.read_bvh()
+        nodes_p, recs_p = part.read_bvh()
+        assert bitwise_equal(nodes_p, nodes_f) and bitwise_equal(recs_p, recs_f)
+        assert bitwise_equal(part.read_bvh_wide(), full.read_bvh_wide())
+        # a second, different move of the same meshes, then back: still the full update's tree
+        part.update_vertex_range(scene, v_lo, v_hi - v_lo + 1, m0, m1 - m0)
+        full.update_vertices(scene)
+        assert bitwise_equal(part.read_bvh()[0], full.read_bvh()[0]) and bitwise_equal(part.read_bvh_wide(), full.read_bvh_wide())
+        # the range must hold exactly the moved meshes' vertices
+        with pytest.raises(rt.RtError) as e:
+            part.update_vertex_range(moved, v_lo + 1, v_hi - v_lo, m0, m1 - m0)        # misses a vertex of mesh m0
+        assert e.value.status == rt.RT_ERR_SCENE
+        with pytest.raises(rt.RtError) as e:
+            part.update_vertex_range(moved, v_lo, v_hi - v_lo + 2, m0, m1 - m0)        # reaches into mesh m1's vertices
+        assert e.value.status == rt.RT_ERR_SCENE
+        with pytest.raises(rt.RtError) as e:
+            part.update_vertex_range(moved, v_lo, v_hi - v_lo + 1, m0, len(scene.meshes))   # mesh range out of bounds
+        assert e.value.status == rt.RT_ERR_SCENE
+        bad = rt.Scene(scene.triangles, moved.meshes, moved.vertices.copy(), scene.materials)
+        bad.vertices["pos"][v_lo + 3] = np.inf
+        with pytest.raises(rt.RtError) as e:
+            part.update_vertex_range(bad, v_lo, v_hi - v_lo + 1, m0, m1 - m0)
+        assert e.value.status == rt.RT_ERR_SCENE
+        assert bitwise_equal(part.read_bvh()[0], full.read_bvh()[0])                    # refused calls changed nothing
 
 
 def test_edge_cases_empty_scene_not_ready_and_bad_arguments():

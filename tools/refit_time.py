@@ -7,6 +7,20 @@ app = rt.App(); app.spawn_sphere_field(10000, 0x5EED0002, 5); app.camera_frame_s
 sc = app.prepare_meshinfo(); m, p = app.camera_view()
 moved = rt.Scene(sc.triangles, sc.meshes.copy(), sc.vertices.copy(), sc.materials)
 moved.vertices["pos"][:, 1] += 0.25; moved.meshes["aabb_min"][:, 1] += 0.25; moved.meshes["aabb_max"][:, 1] += 0.25
+# the dirty-mesh form: one sphere (mesh 4321) of the 10,000 moves
+one = rt.Scene(sc.triangles, sc.meshes.copy(), sc.vertices.copy(), sc.materials)
+k = 4321
+mi = one.meshes[k]
+vs = np.unique(one.triangles["indices"][mi["first_tri"]:mi["first_tri"] + mi["tri_count"]])
+one.vertices["pos"][vs, 1] += 0.25; one.meshes["aabb_min"][k, 1] += 0.25; one.meshes["aabb_max"][k, 1] += 0.25
+ctx = rt.Context(0); ctx.upload_scene(sc); ctx.set_view(m, p, 1920, 1080)
+for rep in range(3):
+    t0 = time.perf_counter(); ctx.update_vertex_range(one, int(vs.min()), int(vs.max() - vs.min() + 1), k, 1); dt = time.perf_counter() - t0
+    print("range rt_update_vertex_range (1 of 10,000 spheres, %d vertices) wall %.2f ms, device %.2f ms" % (len(vs), dt * 1e3, ctx.bvh_info().build_ms), flush=True)
+ctx.render(flags=rt.FLAG_SHADOW); prim_r = ctx.read_prim_ids()
+ctx2 = rt.Context(0); ctx2.upload_scene(sc); ctx2.set_view(m, p, 1920, 1080); ctx2.update_vertices(one); ctx2.render(flags=rt.FLAG_SHADOW)
+print("range == full update:", bool((ctx2.read_prim_ids() == prim_r).all()), flush=True)
+ctx.close(); ctx2.close()
 for mode in ("gpu", "host"):
     if mode == "host": os.environ["RT_TUNE_HOST_REFIT"] = "1"
     ctx = rt.Context(0); ctx.upload_scene(sc); ctx.set_view(m, p, 1920, 1080)

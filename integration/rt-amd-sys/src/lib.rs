@@ -65,6 +65,8 @@ extern "C" {
         spheres: *const rt_sphere, sphere_materials: *const u32, n_spheres: usize) -> c_int;
     pub fn rt_update_vertices(ctx: *mut rt_ctx, vertices: *const rt_vertex, n_vertices: usize,
         meshes: *const rt_mesh_info, n_meshes: usize) -> c_int;
+    pub fn rt_update_vertex_range(ctx: *mut rt_ctx, vertices: *const rt_vertex, first_vertex: usize, n_vertices: usize,
+        meshes: *const rt_mesh_info, first_mesh: usize, n_meshes: usize) -> c_int;
     pub fn rt_set_view(ctx: *mut rt_ctx, world_from_clip: *const f32, world_position: *const f32,
         width: u32, height: u32, viewport: *const u32) -> c_int;
     pub fn rt_render(ctx: *mut rt_ctx, params: *const rt_render_params) -> c_int;

@@ -113,7 +113,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--extra-flags", type=lambda v: int(v, 0), default=0,
-                    help="experiments only: OR these RT_FLAG_* bits into every render (e.g. 0x100 = persistent kernel)")
+                    help="experiments only: OR these RT_FLAG_* bits into every render (e.g. 0x100 = static grid, 0x200 = binary tree)")
     args = ap.parse_args()
 
     import torch

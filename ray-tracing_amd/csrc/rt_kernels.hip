@@ -1,6 +1,7 @@
 // rt_kernels.hip -- hand-written HIP kernels for gfx950 (MI355X / CDNA4): the per-pixel hot
 // path of camms205/ray-tracing (assets/shaders/ray_tracing.wgsl:118-211), one thread per ray,
-// wave64 = one 8x8 pixel tile, BVH traversal with an LDS-resident per-lane stack.
+// wave64 = one 8x8 pixel region, traversal of a 4-wide quantised BVH (or the binary tree it was
+// collapsed from) with an LDS-resident per-lane stack; persistent waves fed from per-XCD queues.
 //
 // Float contract (must match oracle/rt_oracle.c bit for bit; built with -ffp-contract=off):
 //   dot = (x*x' + y*y') + z*z' ; cross component = p*q - r*s ; normalize = v / sqrt(dot(v,v));

@@ -57,9 +57,11 @@ struct rt_ctx {
     uint32_t accum_samples = 0;
     bool accum_dirty = false;        // camera moved: the next path-traced frame restarts accumulation
 
-    // path queues (2, ping-pong)
+    // path queues (2, ping-pong) and the per-sample contribution planes of a batch of samples
     QueueMem q[2];
     size_t q_capacity = 0;
+    float *d_contrib = nullptr;
+    uint32_t contrib_planes = 0;
 
     // counters
     unsigned long long *d_cnt = nullptr;
@@ -69,6 +71,7 @@ struct rt_ctx {
 
     RtTune tune{};
     uint32_t tune_wide = 0;               // build and walk the 4-wide quantised tree
+    uint32_t tune_sample_batch = 16;      // path tracing: most samples of a pixel traced per launch (16, 4 or 1 are used)
     RtWideTree wide_host;
 
     // kernel timing
@@ -116,6 +119,7 @@ void free_frame(rt_ctx *c) {
         p = c->q[i].u; free_dev(p); c->q[i].u = nullptr;
     }
     c->q_capacity = 0;
+    p = c->d_contrib; free_dev(p); c->d_contrib = nullptr; c->contrib_planes = 0;
     c->n_px = 0;
 }
 
@@ -139,15 +143,26 @@ RtPathQueue queue_view(const QueueMem &m, size_t cap) {
     return q;
 }
 
-int ensure_queues(rt_ctx *c) {
-    if (c->q_capacity >= c->n_px && c->q[0].f) return RT_OK;
-    for (int i = 0; i < 2; ++i) {
-        void *p = c->q[i].f; free_dev(p);
-        p = c->q[i].u; free_dev(p);
-        HIPCHK(c, hipMalloc((void **)&c->q[i].f, c->n_px * 9 * sizeof(float)));
-        HIPCHK(c, hipMalloc((void **)&c->q[i].u, c->n_px * 2 * sizeof(uint32_t)));
+// path queues for `batch` samples of every pixel in flight, and the batch's per-sample contribution planes
+int ensure_queues(rt_ctx *c, uint32_t batch) {
+    const size_t need = c->n_px * batch;
+    if (c->q_capacity < need || !c->q[0].f) {
+        for (int i = 0; i < 2; ++i) {
+            void *p = c->q[i].f; free_dev(p); c->q[i].f = nullptr;
+            p = c->q[i].u; free_dev(p); c->q[i].u = nullptr;
+        }
+        c->q_capacity = 0;
+        for (int i = 0; i < 2; ++i) {
+            HIPCHK(c, hipMalloc((void **)&c->q[i].f, need * 9 * sizeof(float)));
+            HIPCHK(c, hipMalloc((void **)&c->q[i].u, need * 2 * sizeof(uint32_t)));
+        }
+        c->q_capacity = need;
     }
-    c->q_capacity = c->n_px;
+    if (c->contrib_planes < batch || !c->d_contrib) {
+        void *p = c->d_contrib; free_dev(p); c->d_contrib = nullptr; c->contrib_planes = 0;
+        HIPCHK(c, hipMalloc((void **)&c->d_contrib, need * 16));
+        c->contrib_planes = batch;
+    }
     return RT_OK;
 }
 
@@ -209,6 +224,7 @@ int rt_create(int device_ordinal, rt_ctx **out) {
         c->tune.wide_vote_node = env("RT_TUNE_WIDE_VOTE_NODE", 3, 1, 64);
         c->tune.wide_vote_tri = env("RT_TUNE_WIDE_VOTE_TRI", 1, 1, 64);
         c->tune_wide = env("RT_TUNE_WIDE", 1, 0, 1);
+        c->tune_sample_batch = env("RT_TUNE_SAMPLE_BATCH", 16, 1, 16);
     }
     int rc = RT_OK;
     do {
@@ -712,7 +728,19 @@ int rt_render(rt_ctx *c, const rt_render_params *params) {
     } else {
         if (P.spp == 0) P.spp = 1;
         if (P.max_segments == 0) P.max_segments = 4;   // reference shape: 4 segments (wgsl:185)
-        int rc = ensure_queues(c);
+        // samples are traced 16 or 4 at a time where there are that many (rt_kernels.hip k_path_start): one start launch
+        // and one launch per bounce for k x k samples of every pixel.  Bounded by 64 M queued paths and by
+        // RT_TUNE_SAMPLE_BATCH (1 = one launch per sample).
+        if (c->n_px > ((size_t)1 << 26)) return fail(c, RT_ERR_ARG, "rt_render: path tracing supports at most 2^26 pixels");
+        auto batch_of = [&](uint32_t left) {
+            uint32_t k2 = 1;
+            for (uint32_t cand : {4u, 16u})
+                if (cand <= left && cand <= c->tune_sample_batch && c->n_px * cand <= ((size_t)64 << 20) &&
+                    ((uint64_t)c->V.width << (cand == 4u ? 1 : 2)) * ((uint64_t)c->V.height << (cand == 4u ? 1 : 2)) <= (1ull << 31)) k2 = cand;
+            return k2;
+        };
+        const uint32_t batch = batch_of(P.spp);
+        int rc = ensure_queues(c, batch);
         if (rc != RT_OK) return rc;
         if (!(P.flags & RT_FLAG_ACCUMULATE) || c->accum_dirty) {
             HIPCHK(c, hipMemsetAsync(c->d_accum, 0, c->n_px * 16, c->stream));
@@ -720,23 +748,28 @@ int rt_render(rt_ctx *c, const rt_render_params *params) {
             c->accum_dirty = false;
         }
         RtPathQueue qa = queue_view(c->q[0], c->q_capacity), qb = queue_view(c->q[1], c->q_capacity);
-        uint32_t cap = (uint32_t)((size_t)rtk_primary_blocks(sh) * RT_BLOCK);
-        if (cap > c->n_px) cap = (uint32_t)c->n_px;
+        uint32_t cap1 = (uint32_t)((size_t)rtk_primary_blocks(sh) * RT_BLOCK);
+        if (cap1 > c->n_px) cap1 = (uint32_t)c->n_px;
         if (timed) HIPCHK(c, hipEventRecord(ev0, c->stream));
-        for (uint32_t s = 0; s < P.spp; ++s) {
+        for (uint32_t s = 0, b = 0; s < P.spp; s += b) {
+            b = batch_of(P.spp - s);                       // 16, 4 or 1 samples of every pixel in this round of launches
+            const uint32_t kshift = b == 16u ? 2u : (b == 4u ? 1u : 0u);
+            const uint32_t cap = cap1 * b;
+            HIPCHK(c, hipMemsetAsync(c->d_contrib, 0, c->n_px * 16 * b, c->stream));
             HIPCHK(c, hipMemsetAsync(c->d_cnt + RT_CNT_QUEUE_A, 0, 2 * sizeof(unsigned long long), c->stream));
             HIPCHK(c, rtk_launch_path_start(c->stream, c->S, c->V, sh, P.flags, P.sample_first + s, P.seed, P.stream_id,
-                                            P.max_segments, c->d_accum, qa, c->d_cnt, RT_CNT_QUEUE_A, c->tune));
+                                            P.max_segments, c->d_contrib, (uint32_t)c->n_px, kshift, qa, c->d_cnt, RT_CNT_QUEUE_A, c->tune));
             ++launches;
             int in = RT_CNT_QUEUE_A, out = RT_CNT_QUEUE_B;
             for (uint32_t seg = 1; seg < P.max_segments; ++seg) {
                 HIPCHK(c, hipMemsetAsync(c->d_cnt + out, 0, sizeof(unsigned long long), c->stream));
-                HIPCHK(c, rtk_launch_path_bounce(c->stream, c->S, P.flags, cap, seg + 1 == P.max_segments, c->d_accum,
+                HIPCHK(c, rtk_launch_path_bounce(c->stream, c->S, P.flags, cap, seg + 1 == P.max_segments, c->d_contrib, (uint32_t)c->n_px,
                                                  in == RT_CNT_QUEUE_A ? qa : qb, in == RT_CNT_QUEUE_A ? qb : qa,
                                                  c->d_cnt, in, out, c->tune));
                 ++launches;
                 int tmp = in; in = out; out = tmp;
             }
+            HIPCHK(c, rtk_launch_accumulate_batch(c->stream, c->d_accum, c->d_contrib, c->n_px, b));
         }
         c->accum_samples += P.spp;
         HIPCHK(c, rtk_launch_resolve(c->stream, c->d_accum, c->d_rgba, c->n_px, 0.0f, c->accum_samples));

@@ -30,12 +30,15 @@ hipError_t rtk_launch_primary(hipStream_t st, const RtSceneDev &S, const RtViewD
 
 // Progressive path tracing (loop shape of ray_tracing.wgsl:180-202) as a wavefront:
 // start = ray gen + jitter + first segment; bounce = one further segment for every queued path.
+// A launch covers k x k consecutive samples of every pixel (k = 1 << kshift) on the frame magnified k times; sample slot s
+// adds its light to contrib[s * n_px + pixel] (zeroed by the caller), rtk_launch_accumulate_batch then adds the slots to
+// the running sums in sample order.  The queues must hold k * k * pixels paths.
 hipError_t rtk_launch_path_start(hipStream_t st, const RtSceneDev &S, const RtViewDev &V, const RtShardDev &sh,
                                  uint32_t flags, uint32_t sample, uint32_t seed, uint32_t stream_id,
-                                 uint32_t max_segments, float *accum, RtPathQueue qout,
+                                 uint32_t max_segments, float *contrib, uint32_t n_px, uint32_t kshift, RtPathQueue qout,
                                  unsigned long long *counters, int qout_counter, const RtTune &tune);
 hipError_t rtk_launch_path_bounce(hipStream_t st, const RtSceneDev &S, uint32_t flags, uint32_t capacity,
-                                  int is_last, float *accum, RtPathQueue qin, RtPathQueue qout,
+                                  int is_last, float *contrib, uint32_t n_px, RtPathQueue qin, RtPathQueue qout,
                                   unsigned long long *counters, int qin_counter, int qout_counter, const RtTune &tune);
 
 // f1: refit one tree level (nodes listed in level_nodes) from the vertices now in `verts`; leaf records re-baked.
@@ -56,5 +59,6 @@ hipError_t rtk_launch_wide_requant(hipStream_t st, const RtBvhNode *nodes, const
 
 hipError_t rtk_launch_resolve(hipStream_t st, const float *accum, float *rgba, size_t n_px, float inv_unused,
                               uint32_t total_samples);
+hipError_t rtk_launch_accumulate_batch(hipStream_t st, float *accum, const float *contrib, size_t n_px, uint32_t batch);
 hipError_t rtk_launch_encode_bgra8(hipStream_t st, const float *rgba, uint8_t *bgra, size_t n_px);
 hipError_t rtk_launch_fill_u32(hipStream_t st, uint32_t *p, uint32_t value, size_t n);

@@ -927,6 +927,9 @@ __device__ __forceinline__ f3 rand_hemi(uint32_t &state, f3 n) {  // wgsl:63-74
     return dir;
 }
 
+// a queued path's pixel word: linear pixel index in the low bits, sample slot of the batch above them
+#define RT_PATH_SLOT_SHIFT 26u
+#define RT_PATH_PIXEL_MASK ((1u << RT_PATH_SLOT_SHIFT) - 1u)
 // Wave-level compaction of surviving paths: one ballot, one atomic per wave.
 __device__ __forceinline__ uint32_t queue_slot(unsigned long long *ctr, bool alive) {
     unsigned long long m = __ballot(alive);
@@ -966,11 +969,18 @@ __device__ __forceinline__ bool path_scatter(const RtSceneDev &S, const Hit &h, 
 // persist != 0: one chip-full of blocks strides over the frame's 16x16 pixel blocks; persist == 0
 // (RT_FLAG_STATIC_GRID): one block per pixel block.  (Fed from k_stream's per-XCD queues instead, this kernel
 // ran 10 % slower at 1080p than the static grid.)
+// Samples are traced k x k at a time (k = 1 << kshift: 1, 4 or 16 samples of every pixel per launch): the launch runs on
+// the frame magnified k times -- thread (sx, sy) of that grid is sample slot (sy % k) * k + sx % k of pixel (sx / k, sy / k)
+// -- so a wave's 64 rays cover an eighth (a quarter ...) of the screen edge they would cover at one sample per pixel and
+// walk the tree that much more in step, and a frame takes a quarter (a sixteenth) of the launches and of their tails.
+// Slot s of a pixel adds its light to contrib[s * n_px + pixel] (written at most once per launch: one path per pixel and
+// sample); k_accumulate_batch then adds the slots to the running sums in sample order -- the same additions in the same
+// order as one launch per sample.
 template <bool COUNT>
 __global__ __launch_bounds__(RT_BLOCK, RT_MIN_WAVES) void k_path_start(RtSceneDev S, RtViewDev V, RtShardDev sh, uint32_t nb,
                                                          uint32_t flags, uint32_t sample, uint32_t seed,
                                                          uint32_t stream_id, uint32_t max_segments,
-                                                         float4 *__restrict__ accum, RtPathQueue qo,
+                                                         float4 *__restrict__ contrib, uint32_t n_px, uint32_t kshift, RtPathQueue qo,
                                                          unsigned long long *__restrict__ counters, int qo_ctr,
                                                          uint32_t persist) {
     __shared__ int s_stack[RT_STACK_LDS * RT_BLOCK];
@@ -979,26 +989,32 @@ __global__ __launch_bounds__(RT_BLOCK, RT_MIN_WAVES) void k_path_start(RtSceneDe
     uint32_t n_primary = 0;
     // grid-stride over the nb 16x16 pixel blocks of the frame: with persist the grid is one chip-full of
     // blocks (a multiple of 8, so a block keeps its XCD and the tile map of pixel_of_thread its meaning)
+    // the magnified grid: viewport and shard tiles k times as large, the same tiles owned by the same ranks
+    RtViewDev Vs = V;
+    RtShardDev shs = sh;
+    Vs.vx <<= kshift; Vs.vy <<= kshift; Vs.vw <<= kshift; Vs.vh <<= kshift; shs.tile <<= kshift;
+    const uint32_t kmask = (1u << kshift) - 1u;
     for (uint32_t vb = blockIdx.x; vb < nb; vb += gridDim.x) {
         uint32_t px, py;
-        bool active = pixel_of_thread(V, sh, nb, px, py, vb);
+        bool active = pixel_of_thread(Vs, shs, nb, px, py, vb);
+        const uint32_t slot_s = ((py & kmask) << kshift) | (px & kmask);
+        px >>= kshift; py >>= kshift;
         bool alive = false;
         f3 o, d, col; uint32_t rng = 0, pixel = 0;
         if (active) {
             pixel = py * V.width + px;
             f3 d0;
             ray_gen(V, px, py, o, d0);
-            uint32_t r0 = rt_seed(pixel, sample, seed, stream_id);
+            uint32_t r0 = rt_seed(pixel, sample + slot_s, seed, stream_id);
             float jx = rt_rand(r0), jy = rt_rand(r0);
             d = add(d0, scl(F3(jx, jy, 0.0f), 0.0015f));   // wgsl:184, not renormalised
-            float4 *acc = accum + pixel;
-            float4 a = *acc; a.w = a.w + 1.0f; *acc = a;   // one more sample for this pixel
+            contrib[(size_t)slot_s * n_px + pixel] = make_float4(0.0f, 0.0f, 0.0f, 1.0f);   // this pixel takes one more sample
             Hit h;
             trace<false, COUNT>(S, o, d, flags, stk, h, c);
-            rng = rt_seed(pixel, sample, seed, stream_id);       // recomputed, not kept across the traversal
+            rng = rt_seed(pixel, sample + slot_s, seed, stream_id);       // recomputed, not kept across the traversal
             (void)rt_rand(rng); (void)rt_rand(rng);
             col = F3(1.0f, 1.0f, 1.0f);
-            alive = path_scatter(S, h, o, d, col, rng, accum + pixel) && max_segments > 1;
+            alive = path_scatter(S, h, o, d, col, rng, contrib + (size_t)slot_s * n_px + pixel) && max_segments > 1;
             ++n_primary;
         }
         uint32_t slot = queue_slot(counters + qo_ctr, alive);
@@ -1006,7 +1022,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_MIN_WAVES) void k_path_start(RtSceneDe
             qo.ox[slot] = o.x; qo.oy[slot] = o.y; qo.oz[slot] = o.z;
             qo.dx[slot] = d.x; qo.dy[slot] = d.y; qo.dz[slot] = d.z;
             qo.cr[slot] = col.x; qo.cg[slot] = col.y; qo.cb[slot] = col.z;
-            qo.rng[slot] = rng; qo.pixel[slot] = pixel;
+            qo.rng[slot] = rng; qo.pixel[slot] = pixel | (slot_s << RT_PATH_SLOT_SHIFT);
         }
     }
     wave_sum(counters + RT_CNT_PRIMARY, n_primary);
@@ -1030,7 +1046,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_MIN_WAVES) void k_path_start(RtSceneDe
 // do not.  DESIGN.md section 4.)
 template <bool COUNT>
 __global__ __launch_bounds__(RT_BLOCK, RT_MIN_WAVES) void k_path_bounce(RtSceneDev S, uint32_t flags, int is_last,
-                                                          float4 *__restrict__ accum, RtPathQueue qi, RtPathQueue qo,
+                                                          float4 *__restrict__ contrib, uint32_t n_px, RtPathQueue qi, RtPathQueue qo,
                                                           unsigned long long *__restrict__ counters, int qi_ctr,
                                                           int qo_ctr, uint32_t persist) {
     __shared__ int s_stack[RT_STACK_LDS * RT_BLOCK];
@@ -1050,8 +1066,8 @@ __global__ __launch_bounds__(RT_BLOCK, RT_MIN_WAVES) void k_path_bounce(RtSceneD
             Hit h;
             trace<false, COUNT>(S, o, d, flags, stk, h, c);
             col = F3(qi.cr[i], qi.cg[i], qi.cb[i]);              // fetched after the traversal (registers)
-            rng = qi.rng[i]; pixel = qi.pixel[i];
-            alive = path_scatter(S, h, o, d, col, rng, accum + pixel) && !is_last;
+            rng = qi.rng[i]; pixel = qi.pixel[i];                // pixel | sample slot << RT_PATH_SLOT_SHIFT
+            alive = path_scatter(S, h, o, d, col, rng, contrib + (size_t)(pixel >> RT_PATH_SLOT_SHIFT) * n_px + (pixel & RT_PATH_PIXEL_MASK)) && !is_last;
             ++n_bounce;
         }
         uint32_t slot = queue_slot(counters + qo_ctr, alive);
@@ -1203,6 +1219,22 @@ hipError_t rtk_launch_wide_requant(hipStream_t st, const RtBvhNode *nodes, const
     return hipGetLastError();
 }
 
+// running sums += the batch's per-sample contributions, one sample after the other (the order the reference's
+// loop -- and the oracle -- adds them in); alpha counts samples
+__global__ void k_accumulate_batch(float4 *__restrict__ accum, const float4 *__restrict__ contrib, size_t n_px, uint32_t batch) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < n_px; i += stride) {
+        float4 a = accum[i];
+        for (uint32_t s = 0; s < batch; ++s) {
+            float4 l = contrib[(size_t)s * n_px + i];     // w: 1 where the launch covered the pixel (viewport, shard), else 0
+            a.w = a.w + l.w;
+            a.x = a.x + l.x; a.y = a.y + l.y; a.z = a.z + l.z;
+        }
+        accum[i] = a;
+    }
+}
+
 // ---- A8 resolve: light / f32(samples) (ray_tracing.wgsl:212) ----------------------------------------
 __global__ void k_resolve(const float4 *__restrict__ accum, float4 *__restrict__ rgba, size_t n, float ns) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1290,31 +1322,33 @@ hipError_t rtk_launch_primary(hipStream_t st, const RtSceneDev &S, const RtViewD
 
 hipError_t rtk_launch_path_start(hipStream_t st, const RtSceneDev &S, const RtViewDev &V, const RtShardDev &sh,
                                  uint32_t flags, uint32_t sample, uint32_t seed, uint32_t stream_id,
-                                 uint32_t max_segments, float *accum, RtPathQueue qout,
+                                 uint32_t max_segments, float *contrib, uint32_t n_px, uint32_t kshift, RtPathQueue qout,
                                  unsigned long long *counters, int qout_counter, const RtTune &tune) {
-    uint32_t nb = rtk_primary_blocks(sh);
+    RtShardDev shs = sh;
+    shs.tile <<= kshift;
+    uint32_t nb = rtk_primary_blocks(shs);      // 16x16 blocks of the magnified grid
     if (nb == 0) return hipSuccess;
     uint32_t persist = (flags & (RT_FLAG_STATIC_GRID | RT_FLAG_BRUTE_FORCE)) ? 0u : 1u;
     uint32_t grid = persist && tune.persist_blocks < nb ? (tune.persist_blocks & ~7u) : nb;
     if (grid == 0) grid = nb;
     if (flags & RT_FLAG_COUNTERS)
-        hipLaunchKernelGGL(k_path_start<true>, dim3(grid), dim3(RT_BLOCK), 0, st, S, V, sh, nb, flags, sample, seed, stream_id, max_segments, (float4 *)accum, qout, counters, qout_counter, persist);
+        hipLaunchKernelGGL(k_path_start<true>, dim3(grid), dim3(RT_BLOCK), 0, st, S, V, sh, nb, flags, sample, seed, stream_id, max_segments, (float4 *)contrib, n_px, kshift, qout, counters, qout_counter, persist);
     else
-        hipLaunchKernelGGL(k_path_start<false>, dim3(grid), dim3(RT_BLOCK), 0, st, S, V, sh, nb, flags, sample, seed, stream_id, max_segments, (float4 *)accum, qout, counters, qout_counter, persist);
+        hipLaunchKernelGGL(k_path_start<false>, dim3(grid), dim3(RT_BLOCK), 0, st, S, V, sh, nb, flags, sample, seed, stream_id, max_segments, (float4 *)contrib, n_px, kshift, qout, counters, qout_counter, persist);
     return hipGetLastError();
 }
 
 hipError_t rtk_launch_path_bounce(hipStream_t st, const RtSceneDev &S, uint32_t flags, uint32_t capacity,
-                                  int is_last, float *accum, RtPathQueue qin, RtPathQueue qout,
+                                  int is_last, float *contrib, uint32_t n_px, RtPathQueue qin, RtPathQueue qout,
                                   unsigned long long *counters, int qin_counter, int qout_counter, const RtTune &tune) {
     uint32_t nb = (capacity + RT_BLOCK - 1) / RT_BLOCK;
     if (nb == 0) return hipSuccess;
     uint32_t persist = (flags & (RT_FLAG_STATIC_GRID | RT_FLAG_BRUTE_FORCE)) ? 0u : 1u;
     uint32_t grid = persist && tune.persist_blocks < nb ? tune.persist_blocks : nb;
     if (flags & RT_FLAG_COUNTERS)
-        hipLaunchKernelGGL(k_path_bounce<true>, dim3(grid), dim3(RT_BLOCK), 0, st, S, flags, is_last, (float4 *)accum, qin, qout, counters, qin_counter, qout_counter, persist);
+        hipLaunchKernelGGL(k_path_bounce<true>, dim3(grid), dim3(RT_BLOCK), 0, st, S, flags, is_last, (float4 *)contrib, n_px, qin, qout, counters, qin_counter, qout_counter, persist);
     else
-        hipLaunchKernelGGL(k_path_bounce<false>, dim3(grid), dim3(RT_BLOCK), 0, st, S, flags, is_last, (float4 *)accum, qin, qout, counters, qin_counter, qout_counter, persist);
+        hipLaunchKernelGGL(k_path_bounce<false>, dim3(grid), dim3(RT_BLOCK), 0, st, S, flags, is_last, (float4 *)contrib, n_px, qin, qout, counters, qin_counter, qout_counter, persist);
     return hipGetLastError();
 }
 
@@ -1325,6 +1359,11 @@ static uint32_t stream_grid(size_t n) {
 hipError_t rtk_launch_resolve(hipStream_t st, const float *accum, float *rgba, size_t n_px, float, uint32_t total_samples) {
     if (n_px == 0) return hipSuccess;
     hipLaunchKernelGGL(k_resolve, dim3(stream_grid(n_px)), dim3(256), 0, st, (const float4 *)accum, (float4 *)rgba, n_px, (float)total_samples);
+    return hipGetLastError();
+}
+hipError_t rtk_launch_accumulate_batch(hipStream_t st, float *accum, const float *contrib, size_t n_px, uint32_t batch) {
+    if (n_px == 0 || batch == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_accumulate_batch, dim3(stream_grid(n_px)), dim3(256), 0, st, (float4 *)accum, (const float4 *)contrib, n_px, batch);
     return hipGetLastError();
 }
 hipError_t rtk_launch_encode_bgra8(hipStream_t st, const float *rgba, uint8_t *bgra, size_t n_px) {

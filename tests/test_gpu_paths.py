@@ -64,6 +64,44 @@ def test_path_tracing_matches_the_oracle(segments):
         assert c.node_visits > 0
 
 
+@pytest.mark.parametrize("spp", [4, 5, 21])
+def test_path_tracing_sample_batches_match_the_oracle(spp):
+    """Samples are traced 16 or 4 at a time on a magnified grid (k_path_start), the rest one by one: 4 = one batch of 4,
+    5 = 4 + 1, 21 = 16 + 4 + 1. The running sums must be the sequential ones, bit for bit -- also in a viewport with
+    ragged edges, on a tile shard, and across two accumulating frames."""
+    vp = (7, 5, 50, 27)
+    app = default_app(70, 40, viewport=vp)
+    scene = app.prepare_meshinfo()
+    osc, view = oracle_scene(scene), oracle_view(app, vp)
+    acc_o, segs_o = orc.render_path(osc, view, spp, 4, seed=13, stream=1)
+    with rt.Context(0) as ctx:
+        ctx.upload_scene(scene)
+        m, p = app.camera_view()
+        ctx.set_view(m, p, 70, 40, vp)
+        assert ctx.render(flags=rt.FLAG_PATH_TRACE, spp=spp, max_segments=4, seed=13, stream_id=1) == rt.RT_OK
+        acc_g = ctx.read_accumulation()
+        c = ctx.counters()
+        assert bitwise_equal(acc_g, acc_o) and bitwise_equal(ctx.read_radiance(), orc.resolve(acc_o, spp))
+        assert c.rays_primary == 50 * 27 * spp and c.rays_primary + c.rays_bounce == segs_o
+        outside = np.ones((40, 70), bool)
+        outside[5:32, 7:57] = False
+        assert np.all(acc_g[outside] == 0)                                   # alpha counts samples only where the frame was covered
+        # the same samples as two accumulating frames, split off the batch boundaries
+        first = max(1, spp // 2 - 1)
+        ctx.render(flags=rt.FLAG_PATH_TRACE, spp=first, max_segments=4, seed=13, stream_id=1)
+        ctx.render(flags=rt.FLAG_PATH_TRACE | rt.FLAG_ACCUMULATE, spp=spp - first, sample_first=first, max_segments=4, seed=13, stream_id=1)
+        assert bitwise_equal(ctx.read_accumulation(), acc_o)
+        # a tile shard of it: owned tiles as in the full frame, the others untouched
+        from ray_tracing_amd import multi_gpu
+        ctx.set_view(m, p, 70, 40)
+        ctx.render(flags=rt.FLAG_PATH_TRACE, spp=spp, max_segments=4, seed=13, stream_id=1)
+        full = ctx.read_accumulation()
+        ctx.render(flags=rt.FLAG_PATH_TRACE, spp=spp, max_segments=4, seed=13, stream_id=1, shard_rank=1, shard_count=3, tile_size=16)
+        part = ctx.read_accumulation()
+        mine = multi_gpu.tile_owner(70, 40, 16, 3) == 1
+        assert bitwise_equal(part[mine], full[mine]) and np.all(part[~mine] == 0)
+
+
 def test_progressive_accumulation_and_reset_on_camera_move():
     app = default_app(64, 36)
     scene = app.prepare_meshinfo()

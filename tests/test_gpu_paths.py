@@ -451,6 +451,73 @@ def test_update_vertex_range_refits_only_the_moved_meshes():
         assert bitwise_equal(part.read_bvh()[0], full.read_bvh()[0])                    # refused calls changed nothing
 
 
+@pytest.mark.parametrize("seed", range(8))
+def test_fuzz_wide_tree_binary_tree_and_reference_loop_agree(seed):
+    """Random triangle soups over many scales (slivers, coplanar sheets, coincident and degenerate triangles, a few huge
+    ones around thousands of tiny ones), random and axis-parallel cameras: the wide tree, the binary tree and the
+    reference-shaped two-level loop (RT_FLAG_BRUTE_FORCE, itself pinned to the oracle elsewhere) must give the same
+    primitive, distance and radiance in every pixel, shadow rays included."""
+    rng = np.random.default_rng(1000 + seed)
+    n = int(rng.integers(200, 3000))
+    scale = float(10.0 ** rng.uniform(-3, 4))
+    centre = rng.uniform(-1, 1, 3) * scale * float(rng.choice([0.0, 1.0, 100.0]))
+    c = rng.uniform(-1, 1, (n, 1, 3)) * scale
+    size = (10.0 ** rng.uniform(-3, 0, (n, 1, 1))) * scale
+    tri = c + rng.normal(size=(n, 3, 3)) * size
+    kind = rng.integers(0, 10, n)
+    tri[kind == 0, :, 1] = 0.0                                   # a coplanar sheet at y = 0
+    tri[kind == 1, 2] = tri[kind == 1, 1]                        # degenerate: two equal vertices
+    tri[kind == 2] = tri[np.flatnonzero(kind == 2)[:1]] if (kind == 2).any() else tri[kind == 2]   # coincident copies
+    tri[kind == 3, :, 0] = np.round(tri[kind == 3, :, 0] / scale) * scale    # axis-aligned slivers on grid planes
+    tri += centre
+    verts = np.zeros(3 * n, rt.VERTEX)
+    verts["pos"] = tri.reshape(-1, 3).astype(np.float32)
+    nrm = np.cross(tri[:, 1] - tri[:, 0], tri[:, 2] - tri[:, 0])
+    nrm /= np.maximum(np.linalg.norm(nrm, axis=1, keepdims=True), 1e-30)
+    verts["norm"] = np.repeat(nrm, 3, axis=0).astype(np.float32)
+    tris = np.zeros(n, rt.TRIANGLE)
+    tris["indices"] = np.arange(3 * n, dtype=np.uint32).reshape(n, 3)
+    n_mesh = int(rng.integers(1, 6))
+    cuts = np.sort(rng.integers(0, n + 1, n_mesh - 1))
+    starts = np.concatenate([[0], cuts]).astype(np.uint32)
+    ends = np.concatenate([cuts, [n]]).astype(np.uint32)
+    meshes = np.zeros(n_mesh, rt.MESH_INFO)
+    meshes["first_tri"], meshes["tri_count"] = starts, ends - starts
+    meshes["material"] = np.arange(n_mesh) % 3
+    for k in range(n_mesh):
+        pts = verts["pos"][3 * starts[k]:3 * ends[k]]
+        if len(pts):
+            meshes["aabb_min"][k], meshes["aabb_max"][k] = pts.min(0), pts.max(0)
+    if n_mesh > 1 and seed % 2:                                   # the reference's quirk: a box that does not bound its mesh
+        meshes["aabb_max"][0] = meshes["aabb_min"][0] + (meshes["aabb_max"][0] - meshes["aabb_min"][0]) * np.float32(0.5)
+    mats = np.zeros(3, rt.MATERIAL)
+    mats["color"] = [(0.9, 0.2, 0.2, 1), (0.2, 0.9, 0.2, 1), (0.2, 0.2, 0.9, 1)]
+    scene = rt.Scene(tris, meshes, verts, mats)
+    app = default_app(64, 64)
+    eye = centre + rng.normal(size=3) * scale * float(rng.choice([0.5, 2.0, 30.0]))
+    if seed % 3 == 0:
+        eye = centre + np.array([0.0, 3.0 * scale, 1e-6 * scale])          # straight down: axis-parallel primary rays
+    app.camera_look_at(tuple(eye), tuple(centre), (0, 0, -1) if seed % 3 == 0 else (0, 1, 0))
+    m, p = app.camera_view()
+    with rt.Context(0) as ctx:
+        ctx.upload_scene(scene)
+        ctx.set_view(m, p, 64, 64)
+        out = []
+        for flags in (rt.FLAG_SHADOW, rt.FLAG_SHADOW | rt.FLAG_BINARY_TREE, rt.FLAG_SHADOW | rt.FLAG_BRUTE_FORCE,
+                      rt.FLAG_SHADOW | rt.FLAG_STATIC_GRID):
+            assert ctx.render(flags=flags) == rt.RT_OK
+            out.append((ctx.read_prim_ids(), ctx.read_hit_t(), ctx.read_radiance()))
+        assert (out[0][0] != rt.MISS_PRIM).mean() > 0.01           # the camera does see the soup
+        for o in out[1:]:
+            assert bitwise_equal(o[0], out[0][0]) and bitwise_equal(o[1], out[0][1])
+            assert np.array_equal(np.isnan(o[2]), np.isnan(out[0][2])) and np.array_equal(np.nan_to_num(o[2]), np.nan_to_num(out[0][2]))
+        acc = []
+        for tree in (0, rt.FLAG_BINARY_TREE):
+            assert ctx.render(flags=rt.FLAG_PATH_TRACE | tree, spp=5, max_segments=3, seed=seed) == rt.RT_OK
+            acc.append(ctx.read_accumulation())
+        assert np.array_equal(np.isnan(acc[0]), np.isnan(acc[1])) and np.array_equal(np.nan_to_num(acc[0]), np.nan_to_num(acc[1]))
+
+
 def test_edge_cases_empty_scene_not_ready_and_bad_arguments():
     with rt.Context(0) as ctx:
         assert ctx.render() == rt.RT_NOT_READY                     # no scene, no view

@@ -108,7 +108,8 @@ int rt_set_view(rt_ctx *ctx, const float world_from_clip[16], const float world_
 #define RT_FLAG_NO_MESH_CULL  0x0002u  /* extension: ignore the per-mesh AABB cull (wgsl:155) */
 #define RT_FLAG_BRUTE_FORCE   0x0004u  /* reference-shaped two-level loop (wgsl:150-170), no BVH */
 #define RT_FLAG_COUNTERS      0x0008u  /* instrumented kernels: count node visits / tests */
-#define RT_FLAG_PATH_TRACE    0x0010u  /* progressive path tracing (wgsl:180-202 loop shape) */
+#define RT_FLAG_PATH_TRACE    0x0010u  /* progressive path tracing (wgsl:180-202 loop shape); frames of at most
+                                          2^26 pixels (8K is 2^25): RT_ERR_ARG beyond */
 #define RT_FLAG_ACCUMULATE    0x0020u  /* keep the accumulation buffer from earlier frames */
 #define RT_FLAG_TIME_KERNELS  0x0040u  /* bracket kernels with HIP events (rt_get_counters) */
 #define RT_FLAG_STATIC_GRID   0x0100u  /* primary/shadow rays: one thread per pixel on a hardware-scheduled grid

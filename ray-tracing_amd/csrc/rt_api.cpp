@@ -675,7 +675,10 @@ int rt_render(rt_ctx *c, const rt_render_params *params) {
         P = *params;
     }
     if (!c->has_scene || !c->has_view) return RT_NOT_READY;   // src/node.rs:52-56: skip silently
-    if (P.tile_size == 0) P.tile_size = 64;
+    if (P.shard_count == 0) P.shard_count = 1;
+    // default tile: 64 px when tiles are what ranks own, 32 px when they are only k_stream's unit of work
+    // distribution over the XCD queues (tools/tile_sweep.py: 16 / 32 / 64 / 128 / 256 px: 0.82 / 0.79 / 0.80 / 0.81 / 0.89 ms)
+    if (P.tile_size == 0) P.tile_size = P.shard_count > 1 ? 64 : 32;
     if (P.tile_size % RT_WORK_TILE != 0 || P.tile_size > 4096) return fail(c, RT_ERR_ARG, "rt_render: tile_size must be a multiple of 16");
     if (P.shard_count == 0) P.shard_count = 1;
     if (P.shard_rank >= P.shard_count) return fail(c, RT_ERR_ARG, "rt_render: shard_rank >= shard_count");

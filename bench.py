@@ -289,11 +289,34 @@ def main():
             out["cpu_baseline"] = cb
             if not tiles:
                 # parity gate on the same sample
-                prim_g = ctx.read_prim_ids().ravel()[pix]
-                rgba_g = ctx.read_radiance().reshape(-1, 4)[pix]
+                prim_all, rgba_all = ctx.read_prim_ids(), ctx.read_radiance()
+                prim_g = prim_all.ravel()[pix]
+                rgba_g = rgba_all.reshape(-1, 4)[pix]
                 d = rgba_g.astype(np.float64) - rgba_o.astype(np.float64)
                 out["parity"] = {"prim_id_agreement": float((prim_g == prim_o).mean()),
                                  "radiance_rmse": float(np.sqrt(np.mean(d * d))), "pixels": int(len(pix))}
+                # "additionally time the CPU BVH traversal on full frames" -- the oracle's scalar walk of the
+                # very tree the device holds (read back through the C ABI), whole frame: a second CPU figure, a
+                # full-frame parity check, and the cross-check of the counted visits behind roofline.achieved
+                try:
+                    nodes_h, recs_h = ctx.read_bvh()
+                    wide_h = ctx.read_bvh_wide() if info.n_wide_nodes and not (flags & rt.FLAG_BINARY_TREE) else None
+                    tree = orc.Tree(nodes_h, recs_h, wide_h)
+                    osc = orc.Scene(scene.triangles, scene.meshes, scene.vertices, scene.materials,
+                                    getattr(scene, "spheres", None), getattr(scene, "sphere_materials", None))
+                    t0 = time.perf_counter()
+                    rgba_w, prim_w, _, rays_w, (nv, nt, nc) = orc.render_primary_tree(osc, tree, view, flags & 1, threads=cb["cores"])
+                    dt_w = time.perf_counter() - t0
+                    dw = rgba_all.astype(np.float64) - rgba_w.astype(np.float64)
+                    cb["tree_walk"] = {"value": round(rays_w / dt_w / 1e6, 3), "unit": "Mrays/s", "cores": cb["cores"],
+                                       "sample": f"full frame, {rays_w} rays, oracle walk (orc_hit_tree) of the device's own tree, {dt_w:.1f} s"}
+                    out["parity"]["full_frame"] = {
+                        "prim_id_agreement": float((prim_all == prim_w).mean()), "radiance_rmse": float(np.sqrt(np.mean(dw * dw))),
+                        "pixels": int(prim_all.size),
+                        "counters_equal_oracle_walk": bool((nv, nt, nc) == (cnt.node_visits, cnt.tri_tests, cnt.mesh_aabb_tests))}
+                    del nodes_h, recs_h, wide_h, tree, rgba_w, prim_w, dw
+                except Exception as ex:                                          # never fail the bench line for it
+                    cb["tree_walk"] = {"error": str(ex)[:120]}
         # second denominator: what a plain device-to-device copy reaches on THIS box, read + write bytes
         try:
             src = torch.empty(1 << 28, dtype=torch.float32, device="cuda")       # 1 GiB: beyond the 256 MiB Infinity Cache

@@ -41,6 +41,15 @@ class OHit(C.Structure):
                 ("material", C.c_uint32), ("prim", C.c_uint32)]
 
 
+class OTree(C.Structure):
+    _fields_ = [("nodes", C.c_void_p), ("n_nodes", C.c_size_t), ("wide", C.c_void_p), ("n_wide", C.c_size_t),
+                ("recs", C.c_void_p), ("n_recs", C.c_size_t)]
+
+
+class OWalkCounts(C.Structure):
+    _fields_ = [("node_visits", C.c_uint64), ("tri_tests", C.c_uint64), ("mesh_culls", C.c_uint64)]
+
+
 class OEntity(C.Structure):
     _fields_ = [("positions", C.c_void_p), ("normals", C.c_void_p), ("n_vtx", C.c_uint32),
                 ("indices", C.c_void_p), ("n_idx", C.c_uint32),
@@ -73,6 +82,11 @@ def lib():
     L.orc_render_primary.argtypes = [C.POINTER(OScene), C.POINTER(OView), C.c_uint32, C.c_void_p, C.c_void_p,
                                      C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
     L.orc_render_primary.restype = C.c_uint64
+    L.orc_hit_tree.argtypes = [C.POINTER(OScene), C.POINTER(OTree), fp, fp, C.c_uint32, C.c_int, C.POINTER(OHit),
+                               C.POINTER(OWalkCounts)]
+    L.orc_render_primary_tree.argtypes = [C.POINTER(OScene), C.POINTER(OTree), C.POINTER(OView), C.c_uint32, C.c_void_p,
+                                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.POINTER(OWalkCounts)]
+    L.orc_render_primary_tree.restype = C.c_uint64
     L.orc_next_random.argtypes = [u32p]
     L.orc_next_random.restype = C.c_uint32
     L.orc_rand.argtypes = [u32p]
@@ -115,6 +129,45 @@ class Scene:
         self.c = OScene(self.triangles.ctypes.data, self.triangles.size, self.meshes.ctypes.data, self.meshes.size,
                         self.vertices.ctypes.data, self.vertices.size, self.materials.ctypes.data, self.materials.size,
                         self.spheres.ctypes.data, self.sphere_materials.ctypes.data, self.spheres.size)
+
+
+class Tree:
+    """An acceleration tree as DATA (rt_oracle.h "tree walk"): 64-B binary nodes, 48-B leaf records and, optionally,
+    64-B wide nodes (given => the wide tree is the one walked).  Arrays of any dtype with those item sizes."""
+
+    def __init__(self, nodes, recs, wide=None):
+        self.nodes = np.ascontiguousarray(nodes)
+        self.recs = np.ascontiguousarray(recs)
+        self.wide = None if wide is None else np.ascontiguousarray(wide)
+        assert self.nodes.dtype.itemsize == 64 and self.recs.dtype.itemsize == 48
+        assert self.wide is None or self.wide.dtype.itemsize == 64
+        self.c = OTree(self.nodes.ctypes.data, self.nodes.size,
+                       self.wide.ctypes.data if self.wide is not None else None, self.wide.size if self.wide is not None else 0,
+                       self.recs.ctypes.data, self.recs.size)
+
+
+def hit_tree(scene, tree, o, d, flags=0, any_hit=False):
+    """Returns (hit dict, (node_visits, tri_tests, mesh_culls))."""
+    h, c = OHit(), OWalkCounts()
+    lib().orc_hit_tree(C.byref(scene.c), C.byref(tree.c), _f3(o), _f3(d), flags, int(any_hit), C.byref(h), C.byref(c))
+    return _hit(h), (c.node_visits, c.tri_tests, c.mesh_culls)
+
+
+def render_primary_tree(scene, tree, view, flags=0, threads=8, pixel_list=None):
+    """render_primary through the tree walk.  Returns (rgba, prim, t, rays, (node_visits, tri_tests, mesh_culls))."""
+    c = OWalkCounts()
+    if pixel_list is None:
+        H, W = view.height, view.width
+        rgba, prim, t = np.zeros((H, W, 4), np.float32), np.zeros((H, W), np.uint32), np.zeros((H, W), np.float32)
+        pl_ptr, n = None, 0
+    else:
+        pl = np.ascontiguousarray(pixel_list, dtype=np.uint32)
+        n = pl.size
+        rgba, prim, t = np.zeros((n, 4), np.float32), np.zeros(n, np.uint32), np.zeros(n, np.float32)
+        pl_ptr = pl.ctypes.data
+    rays = lib().orc_render_primary_tree(C.byref(scene.c), C.byref(tree.c), C.byref(view), flags, rgba.ctypes.data,
+                                         prim.ctypes.data, t.ctypes.data, pl_ptr, n, threads, C.byref(c))
+    return rgba, prim, t, int(rays), (int(c.node_visits), int(c.tri_tests), int(c.mesh_culls))
 
 
 def make_view(world_from_clip, world_position, width, height, viewport=None):

@@ -137,6 +137,156 @@ void orc_hit_triangles(const orc_scene *s, const float o[3], const float d[3], u
     *out = hit;
 }
 
+/* ---- tree walk: scalar restatement of the product's traversal (no reference counterpart; rt_oracle.h) ------ */
+#define TW_NONE ((int32_t)0x80000000)
+#define TW_DONE ((int32_t)0x80000001)
+#define TW_STACK 256
+#define TW_INV_MAX 1e30f
+typedef struct { float lo0[3], hi0[3], lo1[3], hi1[3]; int32_t child0, child1; uint32_t spare[2]; } tw_node;
+typedef struct { float org[3], scl[3]; uint32_t lo[3], hi[3]; int32_t child[4]; } tw_wide;
+typedef struct { float a[3], ab[3], ac[3]; uint32_t tri, mesh, seq; } tw_rec;
+typedef struct { int32_t e[TW_STACK]; int sp; } tw_stack;
+
+static inline int32_t tw_pop(tw_stack *st) { return st->sp == 0 ? TW_DONE : st->e[--st->sp]; }
+static inline void tw_push(tw_stack *st, int32_t v) { if (st->sp < TW_STACK) st->e[st->sp] = v; ++st->sp; }
+static inline float tw_ub(uint32_t w, int k) { return (float)((w >> (8 * k)) & 0xFFu); }
+
+/* binary step: both child boxes, nearer first, the other pushed; far distances get 2 ulp of slack */
+static inline int32_t tw_step_binary(const tw_node *N, v3 o, v3 inv, float t, tw_stack *st) {
+    const float limit = t * 1.00001f;
+    float ax0 = (N->lo0[0] - o.x) * inv.x, ax1 = (N->hi0[0] - o.x) * inv.x;
+    float ay0 = (N->lo0[1] - o.y) * inv.y, ay1 = (N->hi0[1] - o.y) * inv.y;
+    float az0 = (N->lo0[2] - o.z) * inv.z, az1 = (N->hi0[2] - o.z) * inv.z;
+    float bx0 = (N->lo1[0] - o.x) * inv.x, bx1 = (N->hi1[0] - o.x) * inv.x;
+    float by0 = (N->lo1[1] - o.y) * inv.y, by1 = (N->hi1[1] - o.y) * inv.y;
+    float bz0 = (N->lo1[2] - o.z) * inv.z, bz1 = (N->hi1[2] - o.z) * inv.z;
+    float tmin0 = fmaxf(fmaxf(fminf(ax0, ax1), fminf(ay0, ay1)), fminf(az0, az1));
+    float tmax0 = fminf(fminf(fmaxf(ax0, ax1), fmaxf(ay0, ay1)), fmaxf(az0, az1));
+    float tmin1 = fmaxf(fmaxf(fminf(bx0, bx1), fminf(by0, by1)), fminf(bz0, bz1));
+    float tmax1 = fminf(fminf(fmaxf(bx0, bx1), fmaxf(by0, by1)), fmaxf(bz0, bz1));
+    tmax0 *= 1.0000005f; tmax1 *= 1.0000005f;
+    int h0 = tmin0 <= tmax0 && tmax0 >= 0.0f && tmin0 <= limit;
+    int h1 = tmin1 <= tmax1 && tmax1 >= 0.0f && tmin1 <= limit;
+    int both = h0 && h1, swap = tmin1 < tmin0;
+    if (both) tw_push(st, swap ? N->child0 : N->child1);
+    if (h0 || h1) return (both ? swap : h1) ? N->child1 : N->child0;
+    return tw_pop(st);
+}
+
+/* wide step: plane = org + byte*scl, distance = fma(byte, A, -B) with A = scl*inv, B = (o - org)*inv and 1/d clamped
+ * to +-1e30; near/far bytes by the sign of 1/d; entry distance clamped to +0; far distance *1.000001, then the limit;
+ * nearest child exactly (three compare-exchanges on the distance bits), the others pushed in the order they end in */
+static inline __attribute__((always_inline)) int32_t tw_step_wide(const tw_wide *W, v3 o, v3 inv, float t, tw_stack *st) {
+    const float limit = t * 1.00001f;
+    const float Ax = W->scl[0] * inv.x, Ay = W->scl[1] * inv.y, Az = W->scl[2] * inv.z;
+    const float Bx = (o.x - W->org[0]) * inv.x, By = (o.y - W->org[1]) * inv.y, Bz = (o.z - W->org[2]) * inv.z;
+    const int sx = inv.x < 0.0f, sy = inv.y < 0.0f, sz = inv.z < 0.0f;
+    const uint32_t nx = sx ? W->hi[0] : W->lo[0], fx = sx ? W->lo[0] : W->hi[0];
+    const uint32_t ny = sy ? W->hi[1] : W->lo[1], fy = sy ? W->lo[1] : W->hi[1];
+    const uint32_t nz = sz ? W->hi[2] : W->lo[2], fz = sz ? W->lo[2] : W->hi[2];
+    uint32_t key[4]; int32_t ref[4];
+    for (int k = 0; k < 4; ++k) {
+        float tn = fmaxf(fmaxf(__builtin_fmaf(tw_ub(nx, k), Ax, -Bx), __builtin_fmaf(tw_ub(ny, k), Ay, -By)), __builtin_fmaf(tw_ub(nz, k), Az, -Bz));
+        float tf = fminf(fminf(__builtin_fmaf(tw_ub(fx, k), Ax, -Bx), __builtin_fmaf(tw_ub(fy, k), Ay, -By)), __builtin_fmaf(tw_ub(fz, k), Az, -Bz));
+        tn = tn > 0.0f ? tn : 0.0f;           /* max(tn, +0): -0 and NaN become +0, so the bits order like the value */
+        tf = fminf(tf * 1.000001f, limit);
+        int hit = tn <= tf;
+        uint32_t bits; memcpy(&bits, &tn, 4);
+        key[k] = hit ? bits : 0xFFFFFFFFu;
+        ref[k] = hit ? W->child[k] : TW_NONE;
+    }
+#define TW_CE(a, b) if (key[b] < key[a]) { uint32_t tk = key[a]; int32_t tr_ = ref[a]; key[a] = key[b]; ref[a] = ref[b]; key[b] = tk; ref[b] = tr_; }
+    TW_CE(0, 1) TW_CE(2, 3) TW_CE(0, 2)
+#undef TW_CE
+    { uint32_t tk = key[1]; int32_t tr_ = ref[1]; key[1] = key[2]; ref[1] = ref[2]; key[2] = tk; ref[2] = tr_; }
+    if (ref[3] != TW_NONE) tw_push(st, ref[3]);
+    if (ref[2] != TW_NONE) tw_push(st, ref[2]);
+    if (ref[1] != TW_NONE) tw_push(st, ref[1]);
+    return ref[0] != TW_NONE ? ref[0] : tw_pop(st);
+}
+
+/* one leaf record against the ray: wgsl:118-139 from (a, ab, ac), or the build-defined sphere test */
+static inline int tw_prim(const tw_rec *R, v3 o, v3 d, float *dst, float *u, float *v) {
+    if (R->mesh == 0xFFFFFFFFu) {
+        v3 oc = sub(o, ld3(R->a));
+        float a = dot(d, d), hb = dot(oc, d), cc = dot(oc, oc) - R->ab[0] * R->ab[0];
+        float disc = hb * hb - a * cc;
+        *dst = (-hb - sqrtf(disc)) / a; *u = 0.0f; *v = 0.0f;
+        return disc >= 0.0f && *dst >= 0.0f;
+    }
+    v3 ab = ld3(R->ab), ac = ld3(R->ac);
+    v3 norm = cross(ab, ac), ao = sub(o, ld3(R->a)), dao = cross(ao, d);
+    float det = -dot(d, norm), inv_det = 1.0f / det;
+    *dst = dot(ao, norm) * inv_det;
+    *u = dot(ac, dao) * inv_det;
+    *v = -dot(ab, dao) * inv_det;
+    float w = 1.0f - *u - *v;
+    return det >= 1e-6f && *dst >= 0.0f && *u >= 0.0f && *v >= 0.0f && w >= 0.0f;
+}
+
+static inline __attribute__((always_inline)) void tw_walk(const orc_scene *s, const orc_tree *tr, const float o_[3], const float d_[3],
+                                                          uint32_t flags, int any_hit, orc_hit *out, orc_walk_counts *cnt) {
+    const int wide = tr->n_wide != 0;
+    const tw_node *nodes = (const tw_node *)tr->nodes;
+    const tw_wide *wnodes = (const tw_wide *)tr->wide;
+    const tw_rec *recs = (const tw_rec *)tr->recs;
+    v3 o = ld3(o_), d = ld3(d_);
+    float t = INFINITY; uint32_t seq = 0xFFFFFFFFu, rec = 0xFFFFFFFFu;
+    uint64_t n_nodes = 0, n_tris = 0, n_culls = 0;
+    memset(out, 0, sizeof *out); out->prim = ORC_MISS_PRIM;
+    if ((wide ? tr->n_wide : tr->n_nodes) != 0) {
+        v3 inv = V(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+        if (wide) inv = V(fminf(fmaxf(inv.x, -TW_INV_MAX), TW_INV_MAX), fminf(fmaxf(inv.y, -TW_INV_MAX), TW_INV_MAX),
+                          fminf(fmaxf(inv.z, -TW_INV_MAX), TW_INV_MAX));
+        tw_stack st; st.sp = 0;
+        int32_t cur = 0;
+        while (cur != TW_DONE) {
+            if (cur >= 0) {
+                ++n_nodes;
+                cur = wide ? tw_step_wide(&wnodes[cur], o, inv, t, &st) : tw_step_binary(&nodes[cur], o, inv, t, &st);
+            } else if (cur == TW_NONE) {
+                cur = tw_pop(&st);
+            } else {
+                uint32_t code = (uint32_t)(~cur), first = code >> 3, left = code & 7u;
+                const tw_rec *R = &recs[first];
+                float dst, u, v;
+                ++n_tris;
+                int ok = tw_prim(R, o, d, &dst, &u, &v);
+                ok = ok && (dst < t || (dst == t && R->seq < seq));
+                if (ok && !(flags & ORC_FLAG_NO_MESH_CULL) && R->mesh != 0xFFFFFFFFu) {   /* per-mesh cull, wgsl:155: exact 1/d */
+                    ok = orc_ray_aabb(o_, d_, s->meshes[R->mesh].aabb_min, s->meshes[R->mesh].aabb_max);
+                    ++n_culls;
+                }
+                if (ok) { t = dst; seq = R->seq; rec = first; }
+                if (ok && any_hit) cur = TW_DONE;
+                else if (left == 0u) cur = tw_pop(&st);
+                else cur = ~(int32_t)(((first + 1u) << 3) | (left - 1u));
+            }
+        }
+    }
+    if (rec != 0xFFFFFFFFu) {      /* point, normal, material of the accepted record: the reference's own arithmetic */
+        const tw_rec *R = &recs[rec];
+        if (R->mesh == 0xFFFFFFFFu) orc_ray_sphere(s, o_, d_, R->tri - (uint32_t)s->n_tri, out);
+        else { orc_ray_triangle(s, o_, d_, R->tri, out); out->material = s->meshes[R->mesh].material; }
+        out->hit = 1; out->t = t;
+    }
+    if (cnt) { cnt->node_visits += n_nodes; cnt->tri_tests += n_tris; cnt->mesh_culls += n_culls; }
+}
+/* the fma of the wide step as ONE instruction where the CPU has it (same result as libm's fmaf, much faster) */
+#if defined(__x86_64__)
+__attribute__((target("fma"))) static void tw_walk_fma(const orc_scene *s, const orc_tree *tr, const float o[3], const float d[3],
+                                                       uint32_t flags, int any_hit, orc_hit *out, orc_walk_counts *cnt) {
+    tw_walk(s, tr, o, d, flags, any_hit, out, cnt);
+}
+#endif
+void orc_hit_tree(const orc_scene *s, const orc_tree *tr, const float o[3], const float d[3], uint32_t flags,
+                  int any_hit, orc_hit *out, orc_walk_counts *cnt) {
+#if defined(__x86_64__)
+    if (__builtin_cpu_supports("fma")) { tw_walk_fma(s, tr, o, d, flags, any_hit, out, cnt); return; }
+#endif
+    tw_walk(s, tr, o, d, flags, any_hit, out, cnt);
+}
+
 /* ---- A6 shade: wgsl:203-211 --------------------------------------------------------------- */
 void orc_shade(const orc_scene *s, const orc_hit *h, float rgba[4]) {
     if (h->hit) {
@@ -159,19 +309,21 @@ void orc_shade(const orc_scene *s, const orc_hit *h, float rgba[4]) {
 /* one pixel of the live path, plus the build-defined shadow ray:
  * origin = point + normal*1e-3, direction +Y (the direction the reference shades against,
  * wgsl:208); occluded => rgba *= 0.25. */
-static uint32_t trace_pixel(const orc_scene *s, const orc_view *v, uint32_t flags, uint32_t px, uint32_t py,
-                            float rgba[4], uint32_t *prim, float *t) {
+static uint32_t trace_pixel(const orc_scene *s, const orc_tree *tr, orc_walk_counts *cnt, const orc_view *v, uint32_t flags,
+                            uint32_t px, uint32_t py, float rgba[4], uint32_t *prim, float *t) {
     float o[3], d[3];
     orc_hit h;
     uint32_t rays = 1;
     orc_ray_gen(v, px, py, o, d);
-    orc_hit_triangles(s, o, d, flags, &h);
+    if (tr) orc_hit_tree(s, tr, o, d, flags, 0, &h, cnt);
+    else orc_hit_triangles(s, o, d, flags, &h);
     orc_shade(s, &h, rgba);
     if (h.hit && (flags & ORC_FLAG_SHADOW)) {
         float so[3], sd[3] = {0.0f, 1.0f, 0.0f};
         orc_hit sh;
         st3(so, add(ld3(h.point), scl(ld3(h.normal), ORC_SHADOW_EPS)));
-        orc_hit_triangles(s, so, sd, flags, &sh);
+        if (tr) orc_hit_tree(s, tr, so, sd, flags, 1, &sh, cnt);   /* hit_triangles(ray).hit: any accepted hit answers it */
+        else orc_hit_triangles(s, so, sd, flags, &sh);
         rays = 2;
         if (sh.hit)
             for (int k = 0; k < 4; ++k) rgba[k] = rgba[k] * ORC_SHADOW_ATTEN;
@@ -188,6 +340,8 @@ typedef struct {
     uint64_t rays;
     /* path */
     uint32_t spp, sample_first, max_segments, seed, stream; float *accum;
+    /* tree walk (NULL: the reference-shaped loop) */
+    const orc_tree *tr; orc_walk_counts cnt;
 } job_t;
 
 static void view_rect(const orc_view *v, uint32_t *x0, uint32_t *y0, uint32_t *w, uint32_t *h) {
@@ -201,10 +355,11 @@ static void *primary_worker(void *arg) {
     uint32_t x0, y0, vw, vh;
     view_rect(j->v, &x0, &y0, &vw, &vh);
     j->rays = 0;
+    memset(&j->cnt, 0, sizeof j->cnt);
     if (j->list) {
         for (size_t i = (size_t)j->tid; i < j->n; i += (size_t)j->nth) {
             uint32_t p = j->list[i], prim; float rgba[4], t;
-            j->rays += trace_pixel(j->s, j->v, j->flags, p % W, p / W, rgba, &prim, &t);
+            j->rays += trace_pixel(j->s, j->tr, &j->cnt, j->v, j->flags, p % W, p / W, rgba, &prim, &t);
             if (j->rgba) memcpy(j->rgba + 4 * i, rgba, sizeof rgba);
             if (j->prim) j->prim[i] = prim;
             if (j->t) j->t[i] = t;
@@ -215,7 +370,7 @@ static void *primary_worker(void *arg) {
         uint32_t py = y0 + row;
         for (uint32_t px = x0; px < x0 + vw; ++px) {
             size_t i = (size_t)py * W + px; uint32_t prim; float rgba[4], t;
-            j->rays += trace_pixel(j->s, j->v, j->flags, px, py, rgba, &prim, &t);
+            j->rays += trace_pixel(j->s, j->tr, &j->cnt, j->v, j->flags, px, py, rgba, &prim, &t);
             if (j->rgba) memcpy(j->rgba + 4 * i, rgba, sizeof rgba);
             if (j->prim) j->prim[i] = prim;
             if (j->t) j->t[i] = t;
@@ -225,6 +380,7 @@ static void *primary_worker(void *arg) {
 }
 
 static uint64_t run_jobs(job_t *proto, int n_threads, void *(*fn)(void *)) {
+    memset(&proto->cnt, 0, sizeof proto->cnt);
     if (n_threads < 1) n_threads = 1;
     if (n_threads > 256) n_threads = 256;
     job_t *jobs = (job_t *)malloc(sizeof(job_t) * (size_t)n_threads);
@@ -236,24 +392,35 @@ static uint64_t run_jobs(job_t *proto, int n_threads, void *(*fn)(void *)) {
     }
     fn(&jobs[0]);
     for (int i = 1; i < n_threads; ++i) pthread_join(th[i], NULL);
-    for (int i = 0; i < n_threads; ++i) total += jobs[i].rays;
+    for (int i = 0; i < n_threads; ++i) {
+        total += jobs[i].rays;
+        proto->cnt.node_visits += jobs[i].cnt.node_visits; proto->cnt.tri_tests += jobs[i].cnt.tri_tests;
+        proto->cnt.mesh_culls += jobs[i].cnt.mesh_culls;
+    }
     free(jobs); free(th);
     return total;
 }
 
-uint64_t orc_render_primary(const orc_scene *s, const orc_view *v, uint32_t flags,
-                            float *rgba, uint32_t *prim, float *t,
-                            const uint32_t *pixel_list, size_t n_pixels, int n_threads) {
+uint64_t orc_render_primary_tree(const orc_scene *s, const orc_tree *tr, const orc_view *v, uint32_t flags,
+                                 float *rgba, uint32_t *prim, float *t,
+                                 const uint32_t *pixel_list, size_t n_pixels, int n_threads, orc_walk_counts *cnt) {
     job_t j; memset(&j, 0, sizeof j);
     j.s = s; j.v = v; j.flags = flags; j.rgba = rgba; j.prim = prim; j.t = t;
-    j.list = pixel_list; j.n = n_pixels;
+    j.list = pixel_list; j.n = n_pixels; j.tr = tr;
     if (!pixel_list) { /* pixels outside the viewport are left cleared */
         size_t n = (size_t)v->width * v->height;
         if (rgba) memset(rgba, 0, n * 4 * sizeof(float));
         if (prim) memset(prim, 0xFF, n * sizeof(uint32_t));
         if (t) memset(t, 0, n * sizeof(float));
     }
-    return run_jobs(&j, n_threads, primary_worker);
+    uint64_t rays = run_jobs(&j, n_threads, primary_worker);
+    if (cnt) *cnt = j.cnt;
+    return rays;
+}
+uint64_t orc_render_primary(const orc_scene *s, const orc_view *v, uint32_t flags,
+                            float *rgba, uint32_t *prim, float *t,
+                            const uint32_t *pixel_list, size_t n_pixels, int n_threads) {
+    return orc_render_primary_tree(s, NULL, v, flags, rgba, prim, t, pixel_list, n_pixels, n_threads, NULL);
 }
 
 /* ---- A2 RNG: wgsl:38-74 --------------------------------------------------------------------- */

@@ -15,6 +15,8 @@
  *   assets/shaders/ray_tracing.wgsl:38-74    (RNG)
  *   assets/shaders/ray_tracing.wgsl:180-202  (commented path-trace loop shape)
  *   src/ray_tracing.rs:98-169                (prepare_meshinfo)
+ * plus a scalar restatement of the product's tree walk (orc_hit_tree, below; no reference counterpart) that is used to
+ * cross-check the GPU's counted node visits / triangle tests and as a second, tree-based CPU figure;
  * pinned by the hand-worked known-answer tests KAT-1..6 of SURVEY.md section 4
  * (tests/test_oracle_kat.py) and by golden images it produced itself
  * (tests/golden/, made by tests/golden/make_golden.py).
@@ -109,6 +111,32 @@ void orc_shade(const orc_scene *s, const orc_hit *h, float rgba[4]);
 uint64_t orc_render_primary(const orc_scene *s, const orc_view *v, uint32_t flags,
                             float *rgba, uint32_t *prim, float *t,
                             const uint32_t *pixel_list, size_t n_pixels, int n_threads);
+
+/* --- tree walk ("cross-checked by the CPU BVH oracle, which traverses in the same order") ------
+ * NO REFERENCE COUNTERPART (src/bvh.rs:1 is empty): a scalar, one-ray-at-a-time restatement of the walk the
+ * product's kernels make over the product's acceleration tree -- same child order, same slab arithmetic, same
+ * closest-hit rule (lowest t, then lowest position in the reference's loop order, wgsl:164), same per-mesh cull
+ * (wgsl:155) -- so that (1) the walk can be checked against orc_hit_triangles hit for hit on the CPU, and (2) the
+ * node visits / triangle tests the GPU counts for the roofline (rt_get_counters) can be checked to the unit.
+ * The tree is DATA handed in by the test (built by the product's host builder, read through rt_host_bvh /
+ * rt_read_bvh); the layouts are restated here, not included:
+ *   binary node, 64 B: lo0[3] hi0[3] lo1[3] hi1[3] (f32), child0, child1 (i32), 2 spare words
+ *   wide node,   64 B: org[3] scl[3] (f32), lo_x lo_y lo_z hi_x hi_y hi_z (u32, byte k = child k), child[4] (i32)
+ *   leaf record, 48 B: a[3] ab[3] ac[3] (f32), tri, mesh, seq (u32); mesh = 0xFFFFFFFF: sphere (centre, radius in a, ab.x)
+ *   child code: >= 0 node index, < 0 leaf ~((first_record << 3) | (count - 1)), 0x80000000 absent                 */
+typedef struct {
+    const void *nodes;  size_t n_nodes;   /* binary nodes */
+    const void *wide;   size_t n_wide;    /* wide nodes; n_wide != 0 => the wide tree is the one walked */
+    const void *recs;   size_t n_recs;
+} orc_tree;
+typedef struct { uint64_t node_visits, tri_tests, mesh_culls; } orc_walk_counts;
+/* closest hit (any_hit = 0) or first accepted hit (any_hit = 1, shadow rays); counts are ADDED to *cnt */
+void orc_hit_tree(const orc_scene *s, const orc_tree *tr, const float o[3], const float d[3], uint32_t flags,
+                  int any_hit, orc_hit *out, orc_walk_counts *cnt);
+/* orc_render_primary with orc_hit_tree in place of orc_hit_triangles; *cnt (may be NULL) receives the sums */
+uint64_t orc_render_primary_tree(const orc_scene *s, const orc_tree *tr, const orc_view *v, uint32_t flags,
+                                 float *rgba, uint32_t *prim, float *t,
+                                 const uint32_t *pixel_list, size_t n_pixels, int n_threads, orc_walk_counts *cnt);
 
 /* --- RNG (wgsl:38-74), integer core + FP wrappers ---------------------------------- */
 uint32_t orc_next_random(uint32_t *state);

@@ -47,3 +47,45 @@ def test_soup_bvh_matches_oracle_and_brute_force():
         _, rgba_b, prim_b, t_b = gpu_render(app, scene, rt.FLAG_SHADOW | f, ctx=ctx)
         assert bitwise_equal(prim_b, prim_o) and bitwise_equal(t_b, t_o) and bitwise_equal(rgba_b, rgba_o)
     ctx.close()
+
+
+def _analytic_case():
+    app = rt.App()
+    app.spawn_sphere_field(30, 0x5EED0002, 1)
+    app.camera_frame_scene()
+    app.camera_set_target(160, 90)
+    app.prepare_meshinfo()
+    return app, rt.analytic_sphere_field(30, 0x5EED0002)
+
+
+@pytest.mark.parametrize("name", ["default", "soup", "analytic"])
+def test_counters_equal_the_oracle_tree_walk(name):
+    """the node visits / triangle tests behind roofline.achieved are COUNTED by the kernel and cross-checked
+    by the CPU oracle walking the same tree in the same order (oracle/rt_oracle.c orc_hit_tree): equal to the unit,
+    on the wide tree and on the binary tree, from the persistent kernel and from the static grid."""
+    if name == "default":
+        app = default_app(320, 180)
+        scene = app.prepare_meshinfo()
+    elif name == "soup":
+        app = soup_app(40, 0x5EED0003, 160, 90, subdivisions=3)
+        scene = app.prepare_meshinfo()
+    else:
+        app, scene = _analytic_case()
+    osc = orc.Scene(scene.triangles, scene.meshes, scene.vertices, scene.materials,
+                    getattr(scene, "spheres", None), getattr(scene, "sphere_materials", None))
+    view = oracle_view(app)
+    ctx = rt.Context(0)
+    ctx.upload_scene(scene)
+    nodes, recs = ctx.read_bvh()                 # the tree the device walks, read back through the C ABI
+    wide = ctx.read_bvh_wide()
+    assert len(wide) > 0
+    for tree_flag, tree in ((0, orc.Tree(nodes, recs, wide)), (rt.FLAG_BINARY_TREE, orc.Tree(nodes, recs))):
+        for extra, oflags in ((rt.FLAG_SHADOW, orc.FLAG_SHADOW), (rt.FLAG_SHADOW | rt.FLAG_NO_MESH_CULL, orc.FLAG_SHADOW | orc.FLAG_NO_MESH_CULL), (0, 0)):
+            rgba_o, prim_o, t_o, rays_o, (nv, nt, nc) = orc.render_primary_tree(osc, tree, view, oflags)
+            for kernel in (0, rt.FLAG_STATIC_GRID):
+                _, rgba_g, prim_g, t_g = gpu_render(app, scene, extra | tree_flag | kernel | rt.FLAG_COUNTERS, ctx=ctx)
+                c = ctx.counters()
+                assert bitwise_equal(prim_g, prim_o) and bitwise_equal(t_g, t_o) and bitwise_equal(rgba_g, rgba_o)
+                assert c.rays_primary + c.rays_shadow == rays_o
+                assert (c.node_visits, c.tri_tests, c.mesh_aabb_tests) == (nv, nt, nc), (name, tree_flag, extra, kernel)
+    ctx.close()

@@ -103,6 +103,10 @@ def lib():
     L.orc_render_path.argtypes = [C.POINTER(OScene), C.POINTER(OView), C.c_uint32, C.c_uint32, C.c_uint32,
                                   C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_int]
     L.orc_render_path.restype = C.c_uint64
+    L.orc_render_path_tree.argtypes = [C.POINTER(OScene), C.POINTER(OTree), C.POINTER(OView), C.c_uint32, C.c_uint32,
+                                       C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_int,
+                                       C.POINTER(OWalkCounts)]
+    L.orc_render_path_tree.restype = C.c_uint64
     L.orc_resolve.argtypes = [C.c_void_p, C.c_size_t, C.c_uint32, C.c_void_p]
     L.orc_encode_bgra8_srgb.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p]
     L.orc_prepare_meshinfo.argtypes = [C.POINTER(OEntity), C.c_size_t, C.c_void_p, C.POINTER(C.c_size_t),
@@ -252,6 +256,17 @@ def render_path(scene, view, spp, max_segments=4, seed=0, stream=0, sample_first
     segs = lib().orc_render_path(C.byref(scene.c), C.byref(view), flags, spp, sample_first, max_segments, seed,
                                  stream, accum.ctypes.data, threads)
     return accum, int(segs)
+
+
+def render_path_tree(scene, tree, view, spp, max_segments=4, seed=0, stream=0, sample_first=0, flags=0, accum=None, threads=8):
+    """render_path through the tree walk.  Returns (accum, segments, (node_visits, tri_tests, mesh_culls))."""
+    H, W = view.height, view.width
+    if accum is None:
+        accum = np.zeros((H, W, 4), np.float32)
+    c = OWalkCounts()
+    segs = lib().orc_render_path_tree(C.byref(scene.c), C.byref(tree.c), C.byref(view), flags, spp, sample_first,
+                                      max_segments, seed, stream, accum.ctypes.data, threads, C.byref(c))
+    return accum, int(segs), (int(c.node_visits), int(c.tri_tests), int(c.mesh_culls))
 
 
 def resolve(accum, total_samples):

@@ -523,6 +523,7 @@ static void *path_worker(void *arg) {
     uint32_t x0, y0, vw, vh;
     view_rect(j->v, &x0, &y0, &vw, &vh);
     j->rays = 0;
+    memset(&j->cnt, 0, sizeof j->cnt);
     for (uint32_t row = (uint32_t)j->tid; row < vh; row += (uint32_t)j->nth) {
         uint32_t py = y0 + row;
         for (uint32_t px = x0; px < x0 + vw; ++px) {
@@ -541,7 +542,8 @@ static void *path_worker(void *arg) {
                 st3(rd, add(ld3(d), scl(V(jx, jy, 0.0f), 0.0015f)));
                 for (uint32_t i = 0; i < j->max_segments; ++i) {
                     orc_hit rec;
-                    orc_hit_triangles(s, ro, rd, j->flags, &rec);
+                    if (j->tr) orc_hit_tree(s, j->tr, ro, rd, j->flags, 0, &rec, &j->cnt);
+                    else orc_hit_triangles(s, ro, rd, j->flags, &rec);
                     j->rays++;
                     if (rec.hit) {
                         /* record.color = material colour rgb; record.light = 0 (T4 has no emission) */
@@ -563,13 +565,20 @@ static void *path_worker(void *arg) {
     return NULL;
 }
 
+uint64_t orc_render_path_tree(const orc_scene *s, const orc_tree *tr, const orc_view *v, uint32_t flags,
+                              uint32_t spp, uint32_t sample_first, uint32_t max_segments,
+                              uint32_t seed, uint32_t stream, float *accum, int n_threads, orc_walk_counts *cnt) {
+    job_t j; memset(&j, 0, sizeof j);
+    j.s = s; j.v = v; j.flags = flags; j.spp = spp; j.sample_first = sample_first;
+    j.max_segments = max_segments; j.seed = seed; j.stream = stream; j.accum = accum; j.tr = tr;
+    uint64_t rays = run_jobs(&j, n_threads, path_worker);
+    if (cnt) *cnt = j.cnt;
+    return rays;
+}
 uint64_t orc_render_path(const orc_scene *s, const orc_view *v, uint32_t flags,
                          uint32_t spp, uint32_t sample_first, uint32_t max_segments,
                          uint32_t seed, uint32_t stream, float *accum, int n_threads) {
-    job_t j; memset(&j, 0, sizeof j);
-    j.s = s; j.v = v; j.flags = flags; j.spp = spp; j.sample_first = sample_first;
-    j.max_segments = max_segments; j.seed = seed; j.stream = stream; j.accum = accum;
-    return run_jobs(&j, n_threads, path_worker);
+    return orc_render_path_tree(s, NULL, v, flags, spp, sample_first, max_segments, seed, stream, accum, n_threads, NULL);
 }
 
 void orc_resolve(const float *accum, size_t n_px, uint32_t total_samples, float *rgba) {

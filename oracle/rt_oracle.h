@@ -155,6 +155,11 @@ uint32_t orc_seed(uint32_t pixel, uint32_t sample, uint32_t seed, uint32_t strea
 uint64_t orc_render_path(const orc_scene *s, const orc_view *v, uint32_t flags,
                          uint32_t spp, uint32_t sample_first, uint32_t max_segments,
                          uint32_t seed, uint32_t stream, float *accum, int n_threads);
+/* the same through the tree walk (orc_hit_tree in place of orc_hit_triangles): scenes of a size the
+ * reference-shaped loop cannot reach; *cnt (may be NULL) receives the walk's sums */
+uint64_t orc_render_path_tree(const orc_scene *s, const orc_tree *tr, const orc_view *v, uint32_t flags,
+                              uint32_t spp, uint32_t sample_first, uint32_t max_segments,
+                              uint32_t seed, uint32_t stream, float *accum, int n_threads, orc_walk_counts *cnt);
 /* out = accum / total_samples (alpha too). */
 void orc_resolve(const float *accum, size_t n_px, uint32_t total_samples, float *rgba);
 

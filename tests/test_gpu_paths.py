@@ -575,7 +575,8 @@ def test_full_size_properties_on_the_bench_workload():
     """At the bench's full size the oracle is too slow, so size-independent properties are checked:
     (1) BVH path == reference-shaped brute-force loop on a random pixel sample (oracle on the sample),
     (2) per-lane, wave-coherent and persistent kernels agree on the whole 1080p frame, bit for bit,
-    (3) the four tile shards of the frame add up to the frame, (4) counters are consistent."""
+    (3) the four tile shards of the frame add up to the frame, (4) counters are consistent; and, since the oracle can
+    walk the tree too (orc_hit_tree), (5) the whole frame and the counted visits against that walk."""
     app = field_app(10000, 0x5EED0002, 1920, 1080)
     app.camera_frame_scene(1.0)
     scene = app.prepare_meshinfo()
@@ -596,6 +597,11 @@ def test_full_size_properties_on_the_bench_workload():
     for extra in (rt.FLAG_WAVE_TRAVERSAL, rt.FLAG_STATIC_GRID):
         _, rgba2, prim2, t2 = gpu_render(app, scene, rt.FLAG_SHADOW | extra, ctx=ctx)
         assert bitwise_equal(prim2, prim) and bitwise_equal(t2, t) and bitwise_equal(rgba2, rgba)
+    # (5) the whole frame and the counted visits against the oracle's walk of the device's own tree
+    tree = orc.Tree(*ctx.read_bvh(), ctx.read_bvh_wide())
+    rgba_w, prim_w, t_w, rays_w, cnt_w = orc.render_primary_tree(oracle_scene(scene), tree, oracle_view(app), orc.FLAG_SHADOW, threads=16)
+    assert bitwise_equal(prim, prim_w) and bitwise_equal(t, t_w) and bitwise_equal(rgba, rgba_w)
+    assert (c.node_visits, c.tri_tests, c.mesh_aabb_tests) == cnt_w and c.rays_primary + c.rays_shadow == rays_w
     total = np.zeros_like(rgba)
     for rank in range(4):
         _, part, _, _ = gpu_render(app, scene, rt.FLAG_SHADOW, ctx=ctx, shard_rank=rank, shard_count=4)
@@ -615,11 +621,76 @@ def test_soup_1m_triangles_sampled_parity():
     rgba_o, prim_o, t_o, _ = orc.render_primary(oracle_scene(scene), oracle_view(app), orc.FLAG_SHADOW, threads=16, pixel_list=pix)
     agree, rmse = parity(rgba.reshape(-1, 4)[pix], prim.ravel()[pix], rgba_o, prim_o)
     assert agree >= 0.999 and rmse <= 1e-3, (agree, rmse)
-    # path tracing on the big scene: 1 spp, 4 segments, sampled rows against the oracle
-    assert ctx.render(flags=rt.FLAG_PATH_TRACE, spp=1, max_segments=4, seed=1) == rt.RT_OK
+    # the WHOLE frame against the oracle's walk of the device's own tree (oracle/rt_oracle.c orc_hit_tree; the
+    # reference-shaped loop above pins that walk on the sample): results and counted visits
+    osc, view = oracle_scene(scene), oracle_view(app)
+    tree = orc.Tree(*ctx.read_bvh(), ctx.read_bvh_wide())
+    rgba_w, prim_w, t_w, rays_w, cnt_w = orc.render_primary_tree(osc, tree, view, orc.FLAG_SHADOW, threads=16)
+    assert bitwise_equal(prim, prim_w) and bitwise_equal(t, t_w) and bitwise_equal(rgba, rgba_w)
+    gpu_render(app, scene, rt.FLAG_SHADOW | rt.FLAG_COUNTERS, ctx=ctx)
+    c = ctx.counters()
+    assert (c.node_visits, c.tri_tests, c.mesh_aabb_tests) == cnt_w and c.rays_primary + c.rays_shadow == rays_w
+    # path tracing on the big scene (configs[3]'s scene and loop shape): 1 spp, 4 segments, whole frame, bit for bit
+    assert ctx.render(flags=rt.FLAG_PATH_TRACE | rt.FLAG_COUNTERS, spp=1, max_segments=4, seed=1) == rt.RT_OK
     acc = ctx.read_accumulation()
     assert np.all(acc[..., 3] == 1.0) and np.isfinite(acc).all()
+    acc_w, segs_w, cnt_p = orc.render_path_tree(osc, tree, view, spp=1, max_segments=4, seed=1, threads=16)
+    c = ctx.counters()
+    assert bitwise_equal(acc, acc_w)
+    assert c.rays_primary + c.rays_bounce == segs_w and (c.node_visits, c.tri_tests, c.mesh_aabb_tests) == cnt_p
+    # configs[2]: 4 jittered primary rays per pixel (one batch of four on the magnified grid)
+    assert ctx.render(flags=rt.FLAG_PATH_TRACE, spp=4, max_segments=1, seed=3) == rt.RT_OK
+    acc4_w, _, _ = orc.render_path_tree(osc, tree, view, spp=4, max_segments=1, seed=3, threads=16)
+    assert bitwise_equal(ctx.read_accumulation(), acc4_w)
+    # configs[3] at its resolution: 3840x2160, <= 4 segments, 4 of its 64 samples per pixel (one batch of four)
+    app.camera_set_target(3840, 2160)
+    m, p = app.camera_view()
+    ctx.set_view(m, p, 3840, 2160)
+    assert ctx.render(flags=rt.FLAG_PATH_TRACE, spp=4, max_segments=4, seed=9) == rt.RT_OK
+    acc4k_w, segs4k, _ = orc.render_path_tree(osc, tree, oracle_view(app), spp=4, max_segments=4, seed=9, threads=16)
+    c = ctx.counters()
+    assert bitwise_equal(ctx.read_accumulation(), acc4k_w) and c.rays_primary + c.rays_bounce == segs4k
     ctx.close()
+
+
+def test_soup_10m_triangles_path_tracing_whole_frame():
+    """configs[4]'s scene (13,889 icospheres = 10,000,080 triangles) and loop shape (<= 8 segments) at 1080p: the whole
+    frame, bit for bit, against the oracle's walk of the device's own tree, and the counted visits to the unit."""
+    app = soup_app(13889, 0x5EED0005, 1920, 1080)
+    app.camera_frame_scene(1.0)
+    scene = app.prepare_meshinfo()
+    assert len(scene.triangles) == 10000080
+    osc, view = oracle_scene(scene), oracle_view(app)
+    with rt.Context(0) as ctx:
+        ctx.upload_scene(scene)
+        m, p = app.camera_view()
+        ctx.set_view(m, p, 1920, 1080)
+        assert ctx.bvh_info().n_wide_nodes > 0
+        tree = orc.Tree(*ctx.read_bvh(), ctx.read_bvh_wide())
+        assert ctx.render(flags=rt.FLAG_PATH_TRACE | rt.FLAG_COUNTERS, spp=1, max_segments=8, seed=1) == rt.RT_OK
+        acc, c = ctx.read_accumulation(), ctx.counters()
+        acc_w, segs_w, cnt_w = orc.render_path_tree(osc, tree, view, spp=1, max_segments=8, seed=1, threads=16)
+        assert bitwise_equal(acc, acc_w)
+        assert c.rays_primary + c.rays_bounce == segs_w and (c.node_visits, c.tri_tests, c.mesh_aabb_tests) == cnt_w
+        # primary + shadow on the same scene
+        assert ctx.render(flags=rt.FLAG_SHADOW) == rt.RT_OK
+        rgba_w, prim_w, t_w, _, _ = orc.render_primary_tree(osc, tree, view, orc.FLAG_SHADOW, threads=16)
+        assert bitwise_equal(ctx.read_prim_ids(), prim_w) and bitwise_equal(ctx.read_radiance(), rgba_w)
+        # configs[4] at its resolution: 7680x4320, one sample per pixel, <= 8 segments, all 33,177,600 pixels
+        app.camera_set_target(7680, 4320)
+        m8, p8 = app.camera_view()
+        ctx.set_view(m8, p8, 7680, 4320)
+        assert ctx.render(flags=rt.FLAG_PATH_TRACE, spp=1, max_segments=8, seed=2, stream_id=3) == rt.RT_OK
+        acc8 = ctx.read_accumulation()
+        acc8_w, segs8, _ = orc.render_path_tree(osc, tree, oracle_view(app), spp=1, max_segments=8, seed=2, stream=3, threads=16)
+        c = ctx.counters()
+        assert bitwise_equal(acc8, acc8_w) and c.rays_primary + c.rays_bounce == segs8
+        del acc8, acc8_w
+        app.camera_set_target(1920, 1080)
+        # ... and the walk itself pinned by the reference-shaped loop on a pixel sample
+        pix = np.random.default_rng(7).choice(1920 * 1080, 600, replace=False).astype(np.uint32)
+        rgba_o, prim_o, t_o, _ = orc.render_primary(osc, view, orc.FLAG_SHADOW, threads=16, pixel_list=pix)
+        assert bitwise_equal(prim_w.ravel()[pix], prim_o) and bitwise_equal(rgba_w.reshape(-1, 4)[pix], rgba_o)
 
 
 def test_deep_tree_uses_the_private_part_of_the_stack():

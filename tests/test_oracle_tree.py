@@ -108,3 +108,13 @@ def test_tree_walk_edge_cases():
             h, cnt = orc.hit_tree(osc, tree, o, d)
             assert (h["hit"], h["prim"]) == (ref["hit"], ref["prim"]), (o, d)
             assert cnt[0] >= 1
+
+
+def test_path_tracing_through_the_tree_equals_the_reference_shaped_loop():
+    app = soup_app(12, 0x5EED0003, 64, 48, subdivisions=2)
+    scene = app.prepare_meshinfo()
+    osc, view = oracle_scene(scene), oracle_view(app)
+    acc_o, segs_o = orc.render_path(osc, view, spp=3, max_segments=4, seed=7, stream=1, threads=4)
+    for tree in _trees(scene):
+        acc, segs, cnt = orc.render_path_tree(osc, tree, view, spp=3, max_segments=4, seed=7, stream=1, threads=4)
+        assert segs == segs_o and (_bits(acc) == _bits(acc_o)).all() and cnt[0] > 0

@@ -254,15 +254,18 @@ def main():
         ms_per_step = dt / args.steps * 1e3
         value = total_rays * args.steps / dt / 1e6
         achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
-        traffic = None
+        traffic, pmc_extra = None, {}
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
                 if tj.get("workload") == args.workload:
                     traffic = tj.get("hbm_bytes_per_launch")
+                    # VALU utilisation from the same committed PMC passes (north_star: "rocprof counters must show
+                    # achieved HBM GB/s and VALU utilisation"): not measured by this run, quoted from profiles/
+                    pmc_extra = {k: tj[k] for k in ("valu_busy", "valu_lanes_active", "pmc_source") if k in tj}
             except Exception:
-                traffic = None
+                traffic, pmc_extra = None, {}
         out = {
             "metric": "Mrays/s", "value": round(value, 2), "unit": "Mrays/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
@@ -280,7 +283,7 @@ def main():
                          "kernel_ms": round(kernel_ms, 4),
                          "algorithmic_bytes_per_launch": int(alg_bytes),
                          "node_visits": int(cnt.node_visits), "tri_tests": int(cnt.tri_tests),
-                         "bytes_per_ray": round(alg_bytes / max(rays_step, 1), 1)},
+                         "bytes_per_ray": round(alg_bytes / max(rays_step, 1), 1), **pmc_extra},
         }
         if not args.no_cpu_baseline and not spp and world == 1:
             import oracle_py as orc

@@ -18,3 +18,12 @@ for f in glob.glob(os.path.join(root, "*", "**", "*_kernel_trace.csv"), recursiv
             dur.append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
 if dur:
     print(f"avg duration under PMC: {sum(dur)/len(dur)/1e3:.1f} us over {len(dur)} dispatches")
+
+# derived figures (MI355X: 256 CUs x 4 SIMDs; the counters are sums over the 8 XCDs, a wave64 VALU instruction occupies its SIMD 4 cycles)
+if "SQ_ACTIVE_INST_VALU" in out and "GRBM_GUI_ACTIVE" in out and out["GRBM_GUI_ACTIVE"] > 0:
+    simd_cycles = out["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0
+    print(f"derived valu_busy            {out['SQ_ACTIVE_INST_VALU'] * 4.0 / simd_cycles:18.3f}")
+    if "SQ_THREAD_CYCLES_VALU" in out:
+        print(f"derived valu_lanes_active    {out['SQ_THREAD_CYCLES_VALU'] / (64.0 * out['SQ_ACTIVE_INST_VALU']):18.3f}")
+if "FETCH_SIZE" in out and "WRITE_SIZE" in out:
+    print(f"derived hbm_bytes_per_launch {(out['FETCH_SIZE'] + out['WRITE_SIZE']) * 1024.0:18.0f}")

@@ -516,6 +516,16 @@ def test_fuzz_wide_tree_binary_tree_and_reference_loop_agree(seed):
             assert ctx.render(flags=rt.FLAG_PATH_TRACE | tree, spp=5, max_segments=3, seed=seed) == rt.RT_OK
             acc.append(ctx.read_accumulation())
         assert np.array_equal(np.isnan(acc[0]), np.isnan(acc[1])) and np.array_equal(np.nan_to_num(acc[0]), np.nan_to_num(acc[1]))
+        # the oracle's scalar walk of the same trees: the same hits, and the kernel's counted visits to the unit
+        osc, view = oracle_scene(scene), orc.make_view(m, p, 64, 64)
+        nodes, recs = ctx.read_bvh()
+        wide = ctx.read_bvh_wide() if ctx.bvh_info().n_wide_nodes else None
+        for tree_flag, tree in ((0, orc.Tree(nodes, recs, wide)), (rt.FLAG_BINARY_TREE, orc.Tree(nodes, recs))):
+            rgba_w, prim_w, t_w, rays_w, cnt_w = orc.render_primary_tree(osc, tree, view, orc.FLAG_SHADOW)
+            assert bitwise_equal(prim_w, out[0][0]) and bitwise_equal(t_w, out[0][1])
+            assert ctx.render(flags=rt.FLAG_SHADOW | rt.FLAG_COUNTERS | tree_flag) == rt.RT_OK
+            c = ctx.counters()
+            assert (c.node_visits, c.tri_tests, c.mesh_aabb_tests) == cnt_w and c.rays_primary + c.rays_shadow == rays_w
 
 
 def test_edge_cases_empty_scene_not_ready_and_bad_arguments():

@@ -185,6 +185,21 @@ class Scene:
             raise ValueError("one material index per sphere")
 
 
+def scene_rs_default():
+    """The default scene of the reference's orphaned `Scene` resource (src/scene.rs:22-52; dead code there: the module
+    is commented out of src/lib.rs and its imports do not exist): three analytic spheres -- unit spheres at the origin and
+    at (2, 0, -1), a radius-100 "ground" sphere at (0, -101, 0) -- with their albedo as the material colour, taken as
+    written (no colour-space conversion; roughness and the three point lights of :63-67 have no counterpart in the
+    live shader's SimpleMaterial / shading and are dropped).  Build-defined; renders through rt_upload_scene_ex."""
+    spheres = np.zeros(3, SPHERE)
+    spheres["center"] = [(0.0, 0.0, 0.0), (2.0, 0.0, -1.0), (0.0, -101.0, 0.0)]
+    spheres["radius"] = [1.0, 1.0, 100.0]
+    mats = np.zeros(3, MATERIAL)
+    mats["color"] = [(1.0, 0.0, 1.0, 1.0), (0.2, 0.7, 0.1, 1.0), (0.2, 0.3, 6.0, 1.0)]
+    return Scene(np.zeros(0, TRIANGLE), np.zeros(0, MESH_INFO), np.zeros(0, VERTEX), mats, spheres,
+                 np.arange(3, dtype=np.uint32))
+
+
 def analytic_sphere_field(n, seed):
     """SURVEY 8d config 2, variant (ii): the sphere field of App.spawn_sphere_field as ANALYTIC spheres
     (same SplitMix64 stream, so the same centres, radii and colours as the tessellated field) over the same

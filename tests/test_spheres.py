@@ -134,3 +134,36 @@ def test_gpu_analytic_spheres_path_tracing_matches_the_oracle():
         assert bitwise_equal(ctx.read_accumulation(), acc_o)
         c = ctx.counters()
         assert c.rays_primary + c.rays_bounce == segs_o
+
+
+def test_scene_rs_default_spheres_known_answers():
+    """src/scene.rs:22-52 (dead code in the reference): its three analytic spheres through the oracle."""
+    sc = rt.scene_rs_default()
+    osc = orc.Scene(sc.triangles, sc.meshes, sc.vertices, sc.materials, sc.spheres, sc.sphere_materials)
+    h = orc.hit_triangles(osc, [0.0, 0.0, 5.0], [0.0, 0.0, -1.0])      # the unit sphere at the origin, entered at z = 1
+    assert h["hit"] and h["t"] == 4.0 and h["prim"] == 0 and h["material"] == 0 and np.array_equal(h["normal"], [0, 0, 1])
+    h = orc.hit_triangles(osc, [2.0, 5.0, -1.0], [0.0, -1.0, 0.0])     # the second sphere from above
+    assert h["hit"] and h["t"] == 4.0 and h["prim"] == 1
+    h = orc.hit_triangles(osc, [10.0, 5.0, 10.0], [0.0, -1.0, 0.0])    # the radius-100 ground sphere
+    assert h["hit"] and h["prim"] == 2 and abs(h["point"][1] + 2.0) < 0.02
+    assert not orc.hit_triangles(osc, [0.0, 5.0, 5.0], [0.0, 1.0, 0.0])["hit"]
+
+
+@pytest.mark.gpu
+def test_gpu_scene_rs_default_matches_the_oracle():
+    sc = rt.scene_rs_default()
+    osc = orc.Scene(sc.triangles, sc.meshes, sc.vertices, sc.materials, sc.spheres, sc.sphere_materials)
+    app = rt.App(); app.spawn_default_scene(); app.camera_set_target(320, 180)     # the camera of src/main.rs:59-62
+    m, p = app.camera_view()
+    view = orc.make_view(m, p, 320, 180)
+    rgba_o, prim_o, t_o, rays_o = orc.render_primary(osc, view, orc.FLAG_SHADOW)
+    acc_o, segs_o = orc.render_path(osc, view, 4, 4, seed=3)
+    with rt.Context(0) as ctx:
+        ctx.upload_scene(sc)
+        ctx.set_view(m, p, 320, 180)
+        assert ctx.render(flags=rt.FLAG_SHADOW) == rt.RT_OK
+        prim = ctx.read_prim_ids()
+        assert set(np.unique(prim)) == {0, 1, 2, rt.MISS_PRIM}
+        assert bitwise_equal(prim, prim_o) and bitwise_equal(ctx.read_hit_t(), t_o) and bitwise_equal(ctx.read_radiance(), rgba_o)
+        assert ctx.render(flags=rt.FLAG_PATH_TRACE, spp=4, max_segments=4, seed=3) == rt.RT_OK
+        assert bitwise_equal(ctx.read_accumulation(), acc_o)

@@ -758,7 +758,9 @@ int rt_render(rt_ctx *c, const rt_render_params *params) {
             b = batch_of(P.spp - s);                       // 16, 4 or 1 samples of every pixel in this round of launches
             const uint32_t kshift = b == 16u ? 2u : (b == 4u ? 1u : 0u);
             const uint32_t cap = cap1 * b;
-            HIPCHK(c, hipMemsetAsync(c->d_contrib, 0, c->n_px * 16 * b, c->stream));
+            // k_path_start writes every covered (pixel, slot) of the planes; only pixels this call does not cover
+            // (outside the viewport, other ranks' tiles) have to be cleared for k_accumulate_batch
+            if (partial) HIPCHK(c, hipMemsetAsync(c->d_contrib, 0, c->n_px * 16 * b, c->stream));
             HIPCHK(c, hipMemsetAsync(c->d_cnt + RT_CNT_QUEUE_A, 0, 2 * sizeof(unsigned long long), c->stream));
             HIPCHK(c, rtk_launch_path_start(c->stream, c->S, c->V, sh, P.flags, P.sample_first + s, P.seed, P.stream_id,
                                             P.max_segments, c->d_contrib, (uint32_t)c->n_px, kshift, qa, c->d_cnt, RT_CNT_QUEUE_A, c->tune));

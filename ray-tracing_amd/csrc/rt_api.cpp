@@ -43,6 +43,13 @@ struct rt_ctx {
     std::vector<rt_mesh_info> h_meshes;
     std::vector<uint32_t> h_mesh_vlo, h_mesh_vhi;   // per mesh: lowest / highest vertex index its triangles use
     void *d_dirty = nullptr;              // one byte per binary node (rt_update_vertex_range)
+    // rt_update_vertex_range, short-list form (topology only: valid through refits): parent and depth of every binary
+    // node, the wide node its two boxes are slots of, per mesh the nodes that hold one of its records in a leaf child
+    // (CSR), a visit stamp per node; and a device buffer for the list of nodes to redo
+    std::vector<uint32_t> h_parent, h_depth, h_stamp, h_wide_of_bin, h_mesh_node_off, h_mesh_nodes;
+    uint32_t stamp = 0;
+    void *d_list = nullptr; size_t list_capacity = 0;
+    uint32_t tune_refit_list_max = 16384;  // RT_TUNE_REFIT_LIST_MAX: longer lists take the per-level launches (0 = always); tools/refit_time.py
     void *d_level_nodes = nullptr;        // node indices grouped by tree level, deepest level first (GPU refit)
     std::vector<uint32_t> level_count;    // nodes per group, in that order
 
@@ -102,6 +109,7 @@ void free_scene(rt_ctx *c) {
     free_dev(c->d_meshes); free_dev(c->d_verts); free_dev(c->d_mats);
     free_dev(c->d_spheres); free_dev(c->d_sphere_mats); free_dev(c->d_level_nodes);
     free_dev(c->d_wide); free_dev(c->d_wide_src); free_dev(c->d_dirty);
+    free_dev(c->d_list); c->list_capacity = 0;
     c->level_count.clear();
     c->has_scene = false;
     std::memset(&c->S, 0, sizeof c->S);
@@ -218,6 +226,7 @@ int rt_create(int device_ordinal, rt_ctx **out) {
         c->tune.blocks_per_cu = env("RT_TUNE_BLOCKS_PER_CU", 0, 0, 8);
         c->tune.refill_min = env("RT_TUNE_REFILL_MIN", 64, 1, 64);
         c->tune.finish_min = env("RT_TUNE_FINISH_MIN", 64, 1, 64);
+        c->tune_refit_list_max = (uint32_t)env("RT_TUNE_REFIT_LIST_MAX", 16384, 0, 1 << 24);
         c->tune.vote_node = env("RT_TUNE_VOTE_NODE", 3, 1, 64);
         c->tune.vote_tri = env("RT_TUNE_VOTE_TRI", 1, 1, 64);
         c->tune.uni_min = env("RT_TUNE_UNI_MIN", 16, 1, 65);
@@ -476,6 +485,41 @@ int rt_upload_scene_ex(rt_ctx *c, const rt_triangle *tris, size_t n_tris, const 
                 c->h_mesh_vlo[m] = std::min(c->h_mesh_vlo[m], tris[t].indices[k]);
                 c->h_mesh_vhi[m] = std::max(c->h_mesh_vhi[m], tris[t].indices[k]);
             }
+    {   // parent / depth of every binary node (children are stored after their parent), the nodes above each mesh's
+        // records, and the wide node of every binary node
+        const size_t nn = bvh.nodes.size();
+        c->h_parent.assign(nn, 0xFFFFFFFFu); c->h_depth.assign(nn, 0u); c->h_stamp.assign(nn, 0u); c->stamp = 0;
+        c->h_mesh_node_off.assign(n_meshes + 1, 0u);
+        auto each_leaf_mesh = [&](size_t i, auto &&fn) {      // fn(mesh) for the distinct meshes in node i's leaf children
+            const RtBvhNode &N = bvh.nodes[i];
+            uint32_t seen[16]; int ns = 0;
+            for (int32_t code : {N.child0, N.child1}) {
+                if (code >= 0 || code == RT_CHILD_NONE) continue;
+                uint32_t v = (uint32_t)(~code), first = v >> 3, cnt = (v & 7u) + 1u;
+                for (uint32_t k = first; k < first + cnt; ++k) {
+                    const uint32_t m = bvh.recs[k].mesh;
+                    if (m == RT_REC_SPHERE || m >= n_meshes) continue;
+                    bool dup = false;
+                    for (int q = 0; q < ns; ++q) dup = dup || seen[q] == m;
+                    if (!dup) { seen[ns++] = m; fn(m); }
+                }
+            }
+        };
+        for (size_t i = 0; i < nn; ++i) {
+            const RtBvhNode &N = bvh.nodes[i];
+            if (N.child0 >= 0) { c->h_parent[N.child0] = (uint32_t)i; c->h_depth[N.child0] = c->h_depth[i] + 1; }
+            if (N.child1 >= 0) { c->h_parent[N.child1] = (uint32_t)i; c->h_depth[N.child1] = c->h_depth[i] + 1; }
+            each_leaf_mesh(i, [&](uint32_t m) { c->h_mesh_node_off[m + 1]++; });
+        }
+        for (size_t m = 0; m < n_meshes; ++m) c->h_mesh_node_off[m + 1] += c->h_mesh_node_off[m];
+        c->h_mesh_nodes.assign(c->h_mesh_node_off[n_meshes], 0u);
+        std::vector<uint32_t> fill(c->h_mesh_node_off.begin(), c->h_mesh_node_off.end() - 1);
+        for (size_t i = 0; i < nn; ++i) each_leaf_mesh(i, [&](uint32_t m) { c->h_mesh_nodes[fill[m]++] = (uint32_t)i; });
+        c->h_wide_of_bin.assign(nn, 0xFFFFFFFFu);
+        for (size_t w = 0; w < c->wide_host.src.size(); ++w)
+            for (int k = 0; k < 4; ++k)
+                if (c->wide_host.src[w].slot[k] != RT_WIDE_EMPTY) c->h_wide_of_bin[c->wide_host.src[w].slot[k] >> 1] = (uint32_t)w;
+    }
     c->bvh_host = std::move(bvh);
     c->bvh_host_stale = false;
     c->has_scene = true;
@@ -594,22 +638,74 @@ int rt_update_vertex_range(rt_ctx *c, const rt_vertex *verts, size_t first_verte
         }
     HIPCHK(c, hipSetDevice(c->device));
     const size_t nn = c->S.n_nodes;
-    if (!c->d_dirty && nn) HIPCHK(c, hipMalloc(&c->d_dirty, nn));
+    // Which nodes have a moved mesh below them: walked on the host's copy of the topology (mesh-id spans per node), a few
+    // thousand nodes for a mesh of a few hundred triangles.  A short list is redone by ONE launch (k_refit_list); a long
+    // one by the per-level launches over the whole tree with a dirty byte per node.
+    std::vector<uint32_t> list, level_end;
+    uint32_t n_wide_listed = 0;
+    bool by_list = false;
+    if (nn && n_meshes && c->tune_refit_list_max && c->h_parent.size() == nn) {
+        std::vector<std::vector<uint32_t>> per_level;
+        size_t total = 0;
+        by_list = true;
+        if (++c->stamp == 0u) { std::fill(c->h_stamp.begin(), c->h_stamp.end(), 0u); c->stamp = 1u; }
+        for (size_t m = first_mesh; m < first_mesh + n_meshes && by_list; ++m)
+            for (uint32_t q = c->h_mesh_node_off[m]; q < c->h_mesh_node_off[m + 1] && by_list; ++q)
+                for (uint32_t n = c->h_mesh_nodes[q]; n != 0xFFFFFFFFu && c->h_stamp[n] != c->stamp; n = c->h_parent[n]) {   // up to the first node already listed
+                    c->h_stamp[n] = c->stamp;
+                    const uint32_t d = c->h_depth[n];
+                    if (++total > c->tune_refit_list_max || d + 1 >= RT_REFIT_LIST_MAX_LEVELS) { by_list = false; break; }
+                    if (per_level.size() <= d) per_level.resize(d + 1);
+                    per_level[d].push_back(n);
+                }
+        if (by_list) {
+            for (size_t d = per_level.size(); d-- > 0;) {           // deepest level first
+                list.insert(list.end(), per_level[d].begin(), per_level[d].end());
+                level_end.push_back((uint32_t)list.size());
+            }
+            const size_t n_bin = list.size();
+            if (!c->wide_host.nodes.empty()) {
+                std::vector<uint32_t> w;
+                w.reserve(n_bin);
+                for (size_t i = 0; i < n_bin; ++i) if (c->h_wide_of_bin[list[i]] != 0xFFFFFFFFu) w.push_back(c->h_wide_of_bin[list[i]]);
+                std::sort(w.begin(), w.end());
+                w.erase(std::unique(w.begin(), w.end()), w.end());
+                n_wide_listed = (uint32_t)w.size();
+                list.insert(list.end(), w.begin(), w.end());
+            }
+            if (list.size() > c->list_capacity) {
+                HIPCHK(c, hipStreamSynchronize(c->stream));
+                free_dev(c->d_list); c->list_capacity = 0;
+                const size_t cap = std::max<size_t>(list.size() * 2, 4096);
+                HIPCHK(c, hipMalloc(&c->d_list, cap * sizeof(uint32_t)));
+                c->list_capacity = cap;
+            }
+        }
+    }
+    if (!by_list && !c->d_dirty && nn) HIPCHK(c, hipMalloc(&c->d_dirty, nn));
     hipEvent_t e0 = nullptr, e1 = nullptr;
     HIPCHK(c, hipEventCreate(&e0)); HIPCHK(c, hipEventCreate(&e1));
     if (n_verts) HIPCHK(c, hipMemcpyAsync((rt_vertex *)c->d_verts + first_vertex, verts, n_verts * sizeof(rt_vertex), hipMemcpyHostToDevice, c->stream));
     if (n_meshes) HIPCHK(c, hipMemcpyAsync((rt_mesh_info *)c->d_meshes + first_mesh, meshes, n_meshes * sizeof(rt_mesh_info), hipMemcpyHostToDevice, c->stream));
+    if (by_list && !list.empty()) HIPCHK(c, hipMemcpyAsync(c->d_list, list.data(), list.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipEventRecord(e0, c->stream));
-    if (nn) HIPCHK(c, hipMemsetAsync(c->d_dirty, 0, nn, c->stream));
-    size_t off = 0;
-    for (uint32_t cnt : c->level_count) {
-        HIPCHK(c, rtk_launch_refit_level_dirty(c->stream, (RtBvhNode *)c->d_nodes, (RtTriRecord *)c->d_recs, (const rt_triangle *)c->d_tris,
-                                               (const rt_vertex *)c->d_verts, (const uint32_t *)c->d_level_nodes + off, cnt,
-                                               (uint32_t)first_mesh, (uint32_t)(first_mesh + n_meshes), (uint8_t *)c->d_dirty));
-        off += cnt;
+    if (by_list) {
+        if (!level_end.empty())
+            HIPCHK(c, rtk_launch_refit_list(c->stream, (RtBvhNode *)c->d_nodes, (RtTriRecord *)c->d_recs, (const rt_triangle *)c->d_tris,
+                                            (const rt_vertex *)c->d_verts, (const uint32_t *)c->d_list, level_end.data(), (uint32_t)level_end.size(),
+                                            (const RtWideSrc *)c->d_wide_src, (RtWideNode *)c->d_wide, n_wide_listed));
+    } else {
+        if (nn) HIPCHK(c, hipMemsetAsync(c->d_dirty, 0, nn, c->stream));
+        size_t off = 0;
+        for (uint32_t cnt : c->level_count) {
+            HIPCHK(c, rtk_launch_refit_level_dirty(c->stream, (RtBvhNode *)c->d_nodes, (RtTriRecord *)c->d_recs, (const rt_triangle *)c->d_tris,
+                                                   (const rt_vertex *)c->d_verts, (const uint32_t *)c->d_level_nodes + off, cnt,
+                                                   (uint32_t)first_mesh, (uint32_t)(first_mesh + n_meshes), (uint8_t *)c->d_dirty));
+            off += cnt;
+        }
+        HIPCHK(c, rtk_launch_wide_requant_dirty(c->stream, (const RtBvhNode *)c->d_nodes, (const RtWideSrc *)c->d_wide_src,
+                                                (RtWideNode *)c->d_wide, (uint32_t)c->wide_host.nodes.size(), (const uint8_t *)c->d_dirty));
     }
-    HIPCHK(c, rtk_launch_wide_requant_dirty(c->stream, (const RtBvhNode *)c->d_nodes, (const RtWideSrc *)c->d_wide_src,
-                                            (RtWideNode *)c->d_wide, (uint32_t)c->wide_host.nodes.size(), (const uint8_t *)c->d_dirty));
     HIPCHK(c, hipEventRecord(e1, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));   // host arrays are borrowed for this call only
     float ms = 0.0f;

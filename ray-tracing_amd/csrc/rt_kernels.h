@@ -48,6 +48,11 @@ hipError_t rtk_launch_refit_level(hipStream_t st, RtBvhNode *nodes, RtTriRecord 
 // The same for a dirty range of meshes [mesh_lo, mesh_hi): a leaf is re-baked only if one of its records belongs to
 // such a mesh, an inner child re-read only if it was marked dirty by the level below; dirty[node] (one byte per binary
 // node, zeroed by the caller before the deepest level) is what the next level and the re-quantisation look at.
+// one launch for a short list of nodes (grouped by level, deepest first) followed by the wide nodes to re-quantise
+#define RT_REFIT_LIST_MAX_LEVELS 128
+hipError_t rtk_launch_refit_list(hipStream_t st, RtBvhNode *nodes, RtTriRecord *recs, const rt_triangle *tris, const rt_vertex *verts,
+                                 const uint32_t *list, const uint32_t *level_end, uint32_t n_levels,
+                                 const RtWideSrc *src, RtWideNode *wide, uint32_t n_wide_listed);
 hipError_t rtk_launch_refit_level_dirty(hipStream_t st, RtBvhNode *nodes, RtTriRecord *recs, const rt_triangle *tris,
                                         const rt_vertex *verts, const uint32_t *level_nodes, uint32_t n,
                                         uint32_t mesh_lo, uint32_t mesh_hi, uint8_t *dirty);

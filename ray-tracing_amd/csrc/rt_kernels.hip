@@ -1174,6 +1174,52 @@ __global__ void k_refit_level_dirty(RtBvhNode *nodes, RtTriRecord *recs, const r
     }
     dirty[ni] = any ? 1 : 0;
 }
+// The same for a SHORT list of nodes (the host walks its copy of the tree's topology down to the moved meshes): ONE
+// launch of one workgroup that goes through the levels itself, deepest first, with a barrier between them -- a chain of
+// ~30 launches of a few threads each costs more than the work.  list = [node ids, grouped by level | wide node ids];
+// level_end[l] = end of group l in the list.  Every listed node recomputes both of its boxes (an unmoved side gets the
+// values it already has).  Afterwards the listed wide nodes are re-quantised.
+struct RtRefitLevels { uint32_t n_levels; uint32_t end[RT_REFIT_LIST_MAX_LEVELS]; };
+__global__ __launch_bounds__(1024) void k_refit_list(RtBvhNode *nodes, RtTriRecord *recs, const rt_triangle *__restrict__ tris,
+                                                      const rt_vertex *__restrict__ verts, const uint32_t *__restrict__ list,
+                                                      RtRefitLevels lv, const RtWideSrc *__restrict__ src, RtWideNode *wide,
+                                                      uint32_t n_wide_listed) {
+    uint32_t begin = 0;
+    for (uint32_t l = 0; l < lv.n_levels; ++l) {
+        const uint32_t end = lv.end[l];
+        for (uint32_t i = begin + threadIdx.x; i < end; i += blockDim.x) {
+            RtBvhNode &N = nodes[list[i]];
+            float lo[3], hi[3];
+            if (N.child0 != RT_CHILD_NONE) {
+                box_of_child(N.child0, nodes, recs, tris, verts, lo, hi);
+                for (int k = 0; k < 3; ++k) { N.lo0[k] = lo[k]; N.hi0[k] = hi[k]; }
+            }
+            if (N.child1 != RT_CHILD_NONE) {
+                box_of_child(N.child1, nodes, recs, tris, verts, lo, hi);
+                for (int k = 0; k < 3; ++k) { N.lo1[k] = lo[k]; N.hi1[k] = hi[k]; }
+            }
+        }
+        begin = end;
+        __threadfence_block();    // the next level reads these boxes from other lanes' stores (one workgroup: its scope suffices)
+        __syncthreads();
+    }
+    for (uint32_t i = threadIdx.x; i < n_wide_listed; i += blockDim.x) {
+        const uint32_t w = list[begin + i];
+        RtWideNode W = wide[w];
+        rt_wide_quantise(nodes, src[w], W);
+        wide[w] = W;
+    }
+}
+hipError_t rtk_launch_refit_list(hipStream_t st, RtBvhNode *nodes, RtTriRecord *recs, const rt_triangle *tris, const rt_vertex *verts,
+                                 const uint32_t *list, const uint32_t *level_end, uint32_t n_levels,
+                                 const RtWideSrc *src, RtWideNode *wide, uint32_t n_wide_listed) {
+    if (n_levels == 0 || n_levels > RT_REFIT_LIST_MAX_LEVELS) return n_levels ? hipErrorInvalidValue : hipSuccess;
+    RtRefitLevels lv;
+    lv.n_levels = n_levels;
+    for (uint32_t l = 0; l < RT_REFIT_LIST_MAX_LEVELS; ++l) lv.end[l] = l < n_levels ? level_end[l] : 0u;
+    hipLaunchKernelGGL(k_refit_list, dim3(1), dim3(1024), 0, st, nodes, recs, tris, verts, list, lv, src, wide, n_wide_listed);
+    return hipGetLastError();
+}
 hipError_t rtk_launch_refit_level_dirty(hipStream_t st, RtBvhNode *nodes, RtTriRecord *recs, const rt_triangle *tris,
                                         const rt_vertex *verts, const uint32_t *level_nodes, uint32_t n,
                                         uint32_t mesh_lo, uint32_t mesh_hi, uint8_t *dirty) {

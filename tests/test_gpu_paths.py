@@ -394,9 +394,13 @@ def test_wide_tree_conservative_culling_at_the_extremes(case):
         ctx.close()
 
 
-def test_update_vertex_range_refits_only_the_moved_meshes():
+@pytest.mark.parametrize("list_max", ["16384", "0", "700"])
+def test_update_vertex_range_refits_only_the_moved_meshes(list_max, monkeypatch):
     """f1, dirty-mesh form: four of thirty spheres move; only their vertices are sent, only their leaves re-baked and only
-    their ancestors refitted -- and the tree (binary and wide) is the one a full rt_update_vertices leaves, bit for bit."""
+    their ancestors refitted -- and the tree (binary and wide) is the one a full rt_update_vertices leaves, bit for bit.
+    Both forms of the device side: one launch over a host-made list of the nodes above the moved meshes (default), and
+    the per-level launches with a dirty byte per node (RT_TUNE_REFIT_LIST_MAX=0, or a list longer than the limit)."""
+    monkeypatch.setenv("RT_TUNE_REFIT_LIST_MAX", list_max)
     app = soup_app(30, 0x5EED0003, 160, 90, subdivisions=3)
     app.camera_frame_scene(1.0)
     scene = app.prepare_meshinfo()

@@ -24,7 +24,7 @@ GlobalTransform make_transform(const float scale[3], const float rot[4], const f
     if (trans) t.translation = V3(trans);
     return t;
 }
-int push_mesh(rth_app *a, Mesh m) { a->app.world.meshes.push_back(std::move(m)); return (int)a->app.world.meshes.size() - 1; }
+int push_mesh(rth_app *a, Mesh m) { a->app.world.meshes.push_back(std::move(m)); a->app.world.asset_generation++; return (int)a->app.world.meshes.size() - 1; }
 }  // namespace
 
 extern "C" {
@@ -86,6 +86,7 @@ int rth_add_material(rth_app *a, const float c[4]) {
     StandardMaterial m;
     std::memcpy(m.base_color_linear, c, 16);
     a->app.world.materials.push_back(m);
+    a->app.world.asset_generation++;
     return (int)a->app.world.materials.size() - 1;
 }
 int rth_spawn(rth_app *a, int mesh, int material, const float scale[3], const float rot[4], const float trans[3]) {
@@ -112,6 +113,7 @@ void rth_clear_world(rth_app *a) {
     if (!a) return;
     a->app.world.meshes.clear(); a->app.world.materials.clear(); a->app.world.entities.clear();
     a->app.world.log.clear();
+    a->app.world.asset_generation++;          // whatever comes next is not what prepare_meshinfo baked
 }
 
 void rth_spawn_default_scene(rth_app *a) { if (a) spawn_default_scene(a->app.world); }

@@ -249,9 +249,59 @@ Mesh icosphere_mesh(float radius, uint32_t subdivisions) {
 }
 
 // ---- P1 prepare_meshinfo: src/ray_tracing.rs:98-169, quirks kept ---------------------------------------
+// vertices and box of one entity, as the loop body of src/ray_tracing.rs:131-149 computes them
+static void bake_entity(const Entity &e, const Mesh &mesh, Vertex *out, size_t nv, float aabb_min[3], float aabb_max[3]) {
+    const GlobalTransform &T = e.transform;
+    Vec3 c0, c1, c2;
+    mat3_from_quat(T.rotation, c0, c1, c2);
+    Vec3 m0 = scl(c0, T.scale.x), m1 = scl(c1, T.scale.y), m2 = scl(c2, T.scale.z);
+    for (size_t i = 0; i < nv; ++i) {
+        Vertex v;
+        std::memset(&v, 0, sizeof v);
+        Vec3 p = add(mat3_mul(m0, m1, m2, mesh.positions[i]), T.translation);   // transform_point (:137)
+        Vec3 n = quat_rotate(T.rotation, mesh.normals[i]);                      // rotate only (:139-141)
+        v.pos[0] = p.x; v.pos[1] = p.y; v.pos[2] = p.z;
+        v.norm[0] = n.x; v.norm[1] = n.y; v.norm[2] = n.z;
+        out[i] = v;
+    }
+    // Cuboid::from_size(half_extents * 2).aabb_3d(translate, rotate) (:148-149): the Aabb's
+    // centre and the transform's scale are ignored
+    Vec3 he = v3((e.aabb.half_extents.x * 2.0f) / 2.0f, (e.aabb.half_extents.y * 2.0f) / 2.0f,
+                 (e.aabb.half_extents.z * 2.0f) / 2.0f);
+    Vec3 half = mat3_mul(vabs(c0), vabs(c1), vabs(c2), he);
+    Vec3 lo = sub(T.translation, half), hi = add(T.translation, half);
+    aabb_min[0] = lo.x; aabb_min[1] = lo.y; aabb_min[2] = lo.z;
+    aabb_max[0] = hi.x; aabb_max[1] = hi.y; aabb_max[2] = hi.z;
+}
+
 void prepare_meshinfo(World &world) {
+    // f1, host side: same entities, same handles, same assets as last time => only the entities that moved are baked
+    // again, in place (hpp: World::Baked).  The resource left behind is byte for byte the one the full pass below leaves.
+    bool same = world.info_generation != 0 && world.baked.size() == world.entities.size() &&
+                world.baked_asset_generation == world.asset_generation && world.baked_meshes == world.meshes.size() &&
+                world.baked_materials == world.materials.size();
+    for (size_t i = 0; same && i < world.entities.size(); ++i)
+        same = world.entities[i].mesh == world.baked[i].mesh && world.entities[i].material == world.baked[i].material;
+    if (same) {
+        bool changed = false;
+        for (size_t i = 0; i < world.entities.size(); ++i) {
+            const Entity &e = world.entities[i];
+            World::Baked &b = world.baked[i];
+            if (b.mesh_info < 0) { world.log += "Mesh missing attribute\n"; continue; }
+            if (std::memcmp(&e.transform, &b.transform, sizeof e.transform) == 0 &&
+                std::memcmp(&e.aabb.half_extents, &b.aabb.half_extents, sizeof e.aabb.half_extents) == 0) continue;
+            MeshInfo &mi = world.ray_tracing_info.meshes[b.mesh_info];
+            bake_entity(e, world.meshes[e.mesh], world.ray_tracing_info.vertices.data() + b.first_vertex, b.n_vertices, mi.aabb_min, mi.aabb_max);
+            b.transform = e.transform; b.aabb = e.aabb;
+            world.moved_meshes.push_back((uint32_t)b.mesh_info);
+            changed = true;
+        }
+        if (changed) world.info_generation++;
+        return;
+    }
     RayTracingInfo info = world.ray_tracing_info;   // `ray_tracing_info.clone()` keeps `count` (:112)
     info.vertices.clear(); info.triangles.clear(); info.meshes.clear(); info.materials.clear();
+    world.baked.clear(); world.moved_meshes.clear();
     uint32_t material_index = 0;
     for (const Entity &e : world.entities) {
         if (e.mesh < 0 || (size_t)e.mesh >= world.meshes.size() || e.material < 0 ||
@@ -262,41 +312,28 @@ void prepare_meshinfo(World &world) {
         SimpleMaterial sm;
         std::memcpy(sm.color, mat.base_color_linear, 16);
         info.materials.push_back(sm);                 // pushed BEFORE the attribute check (:122)
+        World::Baked bk;
+        bk.mesh = e.mesh; bk.material = e.material; bk.transform = e.transform; bk.aabb = e.aabb;
+        bk.first_vertex = 0; bk.n_vertices = 0; bk.mesh_info = -1;
         if (!mesh.has_positions || !mesh.has_normals) {
             world.log += "Mesh missing attribute\n";  // (:127), then `continue`: no MeshInfo, no index bump
+            world.baked.push_back(bk);
             continue;
         }
         size_t vertices_len = info.vertices.size();
-        const GlobalTransform &T = e.transform;
-        Vec3 c0, c1, c2;
-        mat3_from_quat(T.rotation, c0, c1, c2);
-        Vec3 m0 = scl(c0, T.scale.x), m1 = scl(c1, T.scale.y), m2 = scl(c2, T.scale.z);
         size_t nv = std::min(mesh.positions.size(), mesh.normals.size());   // zip() stops at the shorter
-        for (size_t i = 0; i < nv; ++i) {
-            Vertex v;
-            std::memset(&v, 0, sizeof v);
-            Vec3 p = add(mat3_mul(m0, m1, m2, mesh.positions[i]), T.translation);   // transform_point (:137)
-            Vec3 n = quat_rotate(T.rotation, mesh.normals[i]);                      // rotate only (:139-141)
-            v.pos[0] = p.x; v.pos[1] = p.y; v.pos[2] = p.z;
-            v.norm[0] = n.x; v.norm[1] = n.y; v.norm[2] = n.z;
-            info.vertices.push_back(v);
-        }
+        info.vertices.resize(vertices_len + nv);
         if (!mesh.has_indices)
             throw std::runtime_error("prepare_meshinfo: mesh has no indices (reference: unwrap() panic, src/ray_tracing.rs:145)");
         size_t len = mesh.indices.size();
-        // Cuboid::from_size(half_extents * 2).aabb_3d(translate, rotate) (:148-149): the Aabb's
-        // centre and the transform's scale are ignored
-        Vec3 he = v3((e.aabb.half_extents.x * 2.0f) / 2.0f, (e.aabb.half_extents.y * 2.0f) / 2.0f,
-                     (e.aabb.half_extents.z * 2.0f) / 2.0f);
-        Vec3 half = mat3_mul(vabs(c0), vabs(c1), vabs(c2), he);
         MeshInfo mi;
         std::memset(&mi, 0, sizeof mi);
+        bake_entity(e, mesh, info.vertices.data() + vertices_len, nv, mi.aabb_min, mi.aabb_max);
         mi.first_tri = (uint32_t)info.triangles.size();
         mi.tri_count = (uint32_t)len / 3u;
         mi.material = material_index;
-        Vec3 lo = sub(T.translation, half), hi = add(T.translation, half);
-        mi.aabb_min[0] = lo.x; mi.aabb_min[1] = lo.y; mi.aabb_min[2] = lo.z;
-        mi.aabb_max[0] = hi.x; mi.aabb_max[1] = hi.y; mi.aabb_max[2] = hi.z;
+        bk.first_vertex = (uint32_t)vertices_len; bk.n_vertices = (uint32_t)nv; bk.mesh_info = (int)info.meshes.size();
+        world.baked.push_back(bk);
         info.meshes.push_back(mi);
         material_index += 1;
         for (size_t i = 0; i + 2 < len; i += 3) {     // tuples() drops a trailing partial triple (:161)
@@ -308,6 +345,10 @@ void prepare_meshinfo(World &world) {
         }
     }
     world.ray_tracing_info = std::move(info);         // commands.insert_resource (:168)
+    world.baked_asset_generation = world.asset_generation;
+    world.baked_meshes = world.meshes.size(); world.baked_materials = world.materials.size();
+    world.info_topology_generation++;
+    world.info_generation++;
 }
 
 // ---- scenes ---------------------------------------------------------------------------------------------
@@ -412,12 +453,74 @@ static uint64_t fnv(const void *data, size_t n, uint64_t h) {
     return h;
 }
 
+static int set_view_and_render(const View &view, const RayTracingInfo &info, RayTracingPipeline &pipeline, const rt_render_params *params) {
+    uint32_t vp[4] = {view.viewport.x, view.viewport.y, view.viewport.w, view.viewport.h};
+    int rc = rt_set_view(pipeline.ctx, view.world_from_clip, view.world_position, view.width, view.height,
+                         view.has_viewport ? vp : nullptr);                 // bind group 0 + viewport (:58-62,71-76)
+    if (rc != RT_OK) return rc;
+    rt_render_params p;
+    std::memset(&p, 0, sizeof p);
+    if (params) p = *params;
+    p.struct_size = sizeof p;
+    p.frame_count = info.count;
+    return rt_render(pipeline.ctx, &p);                                      // draw(0..3, 0..1) (:77)
+}
+
 int RayTracingPassNode::run(const View &view, World &world, RayTracingPipeline &pipeline,
                             const rt_render_params *params) {   // src/node.rs:29-79
     if (!pipeline.ctx || pipeline.status != RT_OK) return RT_NOT_READY;   // pipeline not ready: skip (:52-56)
     const RayTracingInfo &info = world.ray_tracing_info;
     // The reference re-creates and re-uploads all five bindings every frame (:42-50).  Here the
     // arrays go to the GPU (and the BVH is rebuilt) only when their contents change.
+    if (world.info_generation != 0) {
+        // the resource was written by prepare_meshinfo, which says what it changed: no need to look at the arrays
+        int rc = RT_OK;
+        const size_t nm = info.meshes.size();
+        if (uploaded_generation != 0 && world.info_topology_generation == uploaded_topology_generation) {
+            if (world.info_generation != uploaded_generation) {
+                // vertices / mesh boxes of some entities moved (main.rs rotates the cube every frame, src/main.rs:122-126):
+                // the run of MeshInfo entries from the first to the last moved one, if that is a small part of the scene
+                rc = RT_ERR_SCENE;
+                uint32_t m0 = 0xFFFFFFFFu, m1 = 0;
+                for (uint32_t m : world.moved_meshes) { m0 = std::min(m0, m); m1 = std::max(m1, m + 1); }
+                if (m0 < m1 && m1 <= nm && (size_t)(m1 - m0) * 2 <= nm && mesh_vlo.size() == nm) {
+                    size_t v0 = info.vertices.size(), v1 = 0;
+                    for (size_t m = m0; m < m1; ++m)
+                        if (info.meshes[m].tri_count) { v0 = std::min<size_t>(v0, mesh_vlo[m]); v1 = std::max<size_t>(v1, (size_t)mesh_vhi[m] + 1); }
+                    if (v0 < v1) {
+                        rc = rt_update_vertex_range(pipeline.ctx, info.vertices.data() + v0, v0, v1 - v0, info.meshes.data() + m0, m0, m1 - m0);
+                        if (rc == RT_OK) ++range_updates;
+                        else if (rc != RT_ERR_SCENE) return rc;
+                    }
+                }
+                if (rc != RT_OK) {
+                    rc = rt_update_vertices(pipeline.ctx, info.vertices.data(), info.vertices.size(), info.meshes.data(), info.meshes.size());
+                    if (rc == RT_OK) ++full_updates;
+                    else if (rc != RT_ERR_SCENE) return rc;
+                }
+            }
+        } else rc = RT_ERR_SCENE;
+        if (rc != RT_OK) {        // new topology (or an update the library refused): upload and rebuild
+            rc = rt_upload_scene(pipeline.ctx, info.triangles.data(), info.triangles.size(), info.meshes.data(),
+                                 info.meshes.size(), info.vertices.data(), info.vertices.size(),
+                                 info.materials.data(), info.materials.size());
+            if (rc != RT_OK) return rc;
+            mesh_vlo.assign(nm, 0xFFFFFFFFu);
+            mesh_vhi.assign(nm, 0u);
+            for (size_t m = 0; m < nm; ++m)
+                for (uint32_t t = info.meshes[m].first_tri; t < info.meshes[m].first_tri + info.meshes[m].tri_count; ++t)
+                    for (int k = 0; k < 3; ++k) {
+                        mesh_vlo[m] = std::min(mesh_vlo[m], info.triangles[t].indices[k]);
+                        mesh_vhi[m] = std::max(mesh_vhi[m], info.triangles[t].indices[k]);
+                    }
+        }
+        uploaded_generation = world.info_generation;
+        uploaded_topology_generation = world.info_topology_generation;
+        world.moved_meshes.clear();
+        uploaded_signature = 0;       // the hash path below starts over if the resource is ever filled by hand
+        return set_view_and_render(view, info, pipeline, params);
+    }
+    // a resource filled by other code than prepare_meshinfo: compare by content
     uint64_t sig = 0xCBF29CE484222325ull;
     sig = fnv(info.triangles.data(), info.triangles.size() * sizeof(Triangle), sig);
     sig = fnv(info.meshes.data(), info.meshes.size() * sizeof(MeshInfo), sig);
@@ -487,16 +590,7 @@ int RayTracingPassNode::run(const View &view, World &world, RayTracingPipeline &
                     mesh_vhi[m] = std::max(mesh_vhi[m], info.triangles[t].indices[k]);
                 }
     }
-    uint32_t vp[4] = {view.viewport.x, view.viewport.y, view.viewport.w, view.viewport.h};
-    int rc = rt_set_view(pipeline.ctx, view.world_from_clip, view.world_position, view.width, view.height,
-                         view.has_viewport ? vp : nullptr);                 // bind group 0 + viewport (:58-62,71-76)
-    if (rc != RT_OK) return rc;
-    rt_render_params p;
-    std::memset(&p, 0, sizeof p);
-    if (params) p = *params;
-    p.struct_size = sizeof p;
-    p.frame_count = info.count;
-    return rt_render(pipeline.ctx, &p);                                      // draw(0..3, 0..1) (:77)
+    return set_view_and_render(view, info, pipeline, params);
 }
 
 void RayTracingPlugin::build(App &app) const {   // src/ray_tracing.rs:29-42

@@ -73,6 +73,24 @@ struct World {
     Camera camera;
     RayTracingInfo ray_tracing_info;  // the resource prepare_meshinfo inserts
     std::string log;                  // "Mesh missing attribute" lines (src/ray_tracing.rs:127)
+
+    // f1 ("re-bake only moved meshes"), host side.  prepare_meshinfo remembers what it baked per
+    // entity; while the entity list, its asset handles and the assets themselves stay the same it re-bakes only the
+    // entities whose transform or Aabb changed, in place -- the resource it leaves is the one a full pass would leave.
+    // Code that edits `meshes` / `materials` in place must bump `asset_generation` (the host API does).
+    struct Baked {
+        int mesh, material;
+        GlobalTransform transform;
+        Aabb aabb;
+        uint32_t first_vertex, n_vertices;
+        int mesh_info;                // index of its MeshInfo, -1 if the entity was skipped (missing attribute)
+    };
+    std::vector<Baked> baked;
+    uint64_t asset_generation = 0, baked_asset_generation = ~0ull;
+    size_t baked_meshes = 0, baked_materials = 0;
+    uint64_t info_topology_generation = 0;   // +1 with every full rebuild of ray_tracing_info
+    uint64_t info_generation = 0;            // +1 with every change of ray_tracing_info (0: never written by prepare_meshinfo)
+    std::vector<uint32_t> moved_meshes;      // MeshInfo indices re-baked in place since the pass node last looked
 };
 
 // src/ray_tracing.rs:98-169.  Throws std::runtime_error where the reference panics
@@ -117,6 +135,7 @@ struct RayTracingPipeline {
 
 // src/node.rs:18-80
 struct RayTracingPassNode {
+    uint64_t uploaded_generation = 0, uploaded_topology_generation = 0;   // World::info_*_generation the device holds
     uint64_t uploaded_signature = 0;   // scene re-upload only when the arrays change
     uint64_t topology_signature = 0;   // triangles + mesh ranges + materials: unchanged => refit instead of rebuild
     // what the device holds, to find the meshes that moved since (dirty-mesh update, rt_update_vertex_range)

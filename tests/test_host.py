@@ -132,6 +132,39 @@ def test_prepare_meshinfo_quirks_match_the_oracle():
     assert np.allclose((s.meshes["aabb_min"][2] + s.meshes["aabb_max"][2]) / 2, 0, atol=1e-6)
 
 
+def test_prepare_meshinfo_rebakes_only_what_moved_and_leaves_the_full_result():
+    """f1, host side: with the same entities and assets, prepare_meshinfo re-bakes only the entities
+    whose transform / Aabb changed, in place; what it leaves must be what a full pass (the oracle's) leaves, quirks kept."""
+    rng = np.random.default_rng(3)
+    app = rt.App()
+    mats = [app.add_material(rng.uniform(0, 1, 4)) for _ in range(3)]
+    cube, sph = app.add_cuboid(1, 2, 0.5), app.add_icosphere(0.7, 2)
+    nonorm = app.add_mesh(rng.normal(size=(3, 3)), None, [0, 1, 2])
+    ents = [app.spawn(cube, mats[0], translation=(1, 0, 0)), app.spawn(nonorm, mats[1]),
+            app.spawn(sph, mats[2], translation=(-2, 0, 1)), app.spawn(sph, mats[0], translation=(3, 1, 1))]
+    assert _same(app.prepare_meshinfo(), orc.prepare_meshinfo(app.entities()))
+    for step in range(6):
+        q = rng.normal(size=4)
+        q /= np.linalg.norm(q)
+        k = ents[(0, 2, 3, 2, 0, 3)[step]]
+        app.set_transform(k, scale=rng.uniform(0.5, 2, 3), rotation=q, translation=rng.uniform(-3, 3, 3))
+        if step == 4:
+            app.set_aabb(k, (0, 0, 0), (0.3, 0.2, 0.1))
+        n_log = app.log().count("Mesh missing attribute")
+        s = app.prepare_meshinfo()
+        assert _same(s, orc.prepare_meshinfo(app.entities())), step
+        assert app.log().count("Mesh missing attribute") == n_log + 1          # the skipped entity is reported every pass
+    assert _same(app.prepare_meshinfo(), s)                                      # nothing moved: nothing changes
+    # a new asset, or a world cleared and refilled with as many entities: a full pass again
+    app.spawn(app.add_cuboid(2, 2, 2), mats[1], translation=(0, 5, 0))
+    assert _same(app.prepare_meshinfo(), orc.prepare_meshinfo(app.entities()))
+    app.clear_world()
+    m = app.add_material((1, 1, 1, 1))
+    for k in range(5):
+        app.spawn(app.add_icosphere(0.5 + 0.1 * k, 1), m, translation=(k, 0, 0))
+    assert _same(app.prepare_meshinfo(), orc.prepare_meshinfo(app.entities()))
+
+
 def test_unindexed_mesh_is_the_references_panic():
     app = rt.App()
     m = app.add_material((1, 1, 1, 1))

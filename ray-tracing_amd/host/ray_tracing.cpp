@@ -603,6 +603,8 @@ void RayTracingPlugin::build(App &app) const {   // src/ray_tracing.rs:29-42
 void RayTracingPlugin::finish(App &app) const {  // src/ray_tracing.rs:44-48
     if (!app.has_render_app)
         throw std::runtime_error("RayTracingPlugin::finish: no RenderApp (reference: unwrap() panic, src/ray_tracing.rs:46)");
+    app.pipeline.destroy();                                 // a second finish(): the old context goes, and with it
+    app.node = RayTracingPassNode();                        // everything the node believes the device holds
     app.pipeline = RayTracingPipeline::from_world(app.world, app.device_ordinal);
 }
 

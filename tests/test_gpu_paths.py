@@ -220,6 +220,20 @@ def test_plugin_lifecycle_and_dirty_upload():
     assert bitwise_equal(ctx.read_radiance(), rgba_o3) and bitwise_equal(ctx.read_prim_ids(), prim_o3)
     app.camera_set_graph(False)                                    # Tab: camera back on Core3d (src/main.rs:128-147)
     assert app.update() == rt.RT_NOT_READY
+    app.camera_set_graph(True)
+    # many entities move at once (more than half the scene): the full update; and a material edited in place: a rebuild
+    for e in range(4):
+        app.set_transform(e, translation=(0.3 * e, 0.2, -0.1 * e))
+    assert app.update(flags=rt.FLAG_SHADOW) == rt.RT_OK
+    assert app.update_counts() == (3, 1) and ctx.bvh_info().n_builds == 2
+    scene4 = app.info()
+    rgba_o4, prim_o4, _, _ = orc.render_primary(oracle_scene(scene4), oracle_view(app), orc.FLAG_SHADOW)
+    assert bitwise_equal(ctx.read_radiance(), rgba_o4) and bitwise_equal(ctx.read_prim_ids(), prim_o4)
+    # finish() again (a device lost and found): a new context, everything uploaded again, the same frame
+    app.finish(0)
+    assert app.update(flags=rt.FLAG_SHADOW) == rt.RT_OK
+    ctx = app.ctx()
+    assert ctx.bvh_info().n_builds == 1 and bitwise_equal(ctx.read_radiance(), rgba_o4)
     app.close()
 
 

@@ -9,20 +9,27 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <limits>
+#include <memory>
 #include <thread>
 
 namespace {
 
+// 32 B: the passes over the primitives of the big nodes are memory-bound.  The centroid is 0.5*lo + 0.5*hi wherever it is
+// needed; the mesh of a triangle is found again from seq (its position in the reference's loop order) at the end.
 struct Prim {
-    float lo[3], hi[3], c[3];
-    uint32_t seq, tri, mesh;
+    float lo[3], hi[3];
+    uint32_t seq, tri;
 };
+inline float cen(const Prim &P, int k) { return 0.5f * P.lo[k] + 0.5f * P.hi[k]; }
+constexpr uint32_t kDroppedTri = 0xFFFFFFFFu;
 
 struct TmpNode {
     float lo[3], hi[3];
     int32_t left, right;       // inner: indices of TmpNodes; leaf: -1
     uint32_t first, count;     // leaf: run in the prim array
+    uint32_t inner;            // inner nodes in this subtree, this one included (0 for a leaf)
 };
 
 constexpr int kMaxBins = 64;
@@ -34,6 +41,7 @@ int kBins = 16;           // RT_TUNE_BINS (experiments)
 float kCostNode = 1.0f, kCostTri = 2.0f;
 uint32_t kMaxLeaf = RT_MAX_LEAF;
 constexpr size_t kSpawnMin = 1u << 15;
+constexpr size_t kParallelMin = 1u << 18;   // nodes this big run their passes over the primitives on the spare threads
 
 inline float half_area(const float *lo, const float *hi) {
     float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
@@ -48,7 +56,7 @@ inline void box_grow(float *lo, float *hi, const float *blo, const float *bhi) {
 
 struct Builder {
     std::vector<Prim> prims;
-    std::vector<TmpNode> nodes;
+    std::unique_ptr<TmpNode[]> nodes;      // 2n+1 entries, not zeroed: every node is written by build()
     std::atomic<uint32_t> next_node{0};
     std::atomic<int> free_threads{0};
     std::atomic<uint32_t> max_depth{0};
@@ -60,19 +68,60 @@ struct Builder {
         while (d > cur && !max_depth.compare_exchange_weak(cur, d)) {}
     }
 
+    // spare threads: taken for the passes over a big node's primitives, or for a whole subtree
+    int grab(int want) {
+        int got = 0;
+        while (got < want) {
+            if (free_threads.fetch_sub(1) > 0) ++got;
+            else { free_threads.fetch_add(1); break; }
+        }
+        return got;
+    }
+    template <class F>
+    static void split_run(size_t b, size_t e, int parts, F fn) {      // fn(part, begin, end) on `parts` threads
+        if (parts <= 1) { fn(0, b, e); return; }
+        std::vector<std::thread> th;
+        for (int t = 1; t < parts; ++t) th.emplace_back(fn, t, b + (e - b) * (size_t)t / parts, b + (e - b) * (size_t)(t + 1) / parts);
+        fn(0, b, b + (e - b) / parts);
+        for (auto &t : th) t.join();
+    }
+    struct Bins {
+        uint32_t cnt[3][kMaxBins];
+        float blo[3][kMaxBins][3], bhi[3][kMaxBins][3];
+        void reset(int bins) {
+            for (int ax = 0; ax < 3; ++ax)
+                for (int k = 0; k < bins; ++k) { cnt[ax][k] = 0; box_reset(blo[ax][k], bhi[ax][k]); }
+        }
+    };
+    struct Bounds { float lo[3], hi[3], clo[3], chi[3]; };
+
     // Builds the subtree for prims[b,e) into nodes[ni]; depth = depth of this node (root 0).
+    // The passes over the primitives of a big node (bounds, binning) run on every spare thread: minima, maxima and
+    // counts do not depend on how the run is cut up, so the tree is the one a single thread builds.
     void build(uint32_t ni, size_t b, size_t e, uint32_t depth) {
         TmpNode &N = nodes[ni];
-        box_reset(N.lo, N.hi);
-        float clo[3], chi[3];
-        box_reset(clo, chi);
-        for (size_t i = b; i < e; ++i) {
-            box_grow(N.lo, N.hi, prims[i].lo, prims[i].hi);
-            box_grow(clo, chi, prims[i].c, prims[i].c);
-        }
         size_t n = e - b;
+        const int extra = n >= kParallelMin ? grab((int)std::min<size_t>(n / (kParallelMin / 4), 15)) : 0;
+        const int parts = 1 + extra;
+        float clo[3], chi[3];
+        {
+            Bounds one; std::vector<Bounds> many;       // no heap traffic for the millions of small nodes
+            if (parts > 1) many.resize((size_t)parts);
+            Bounds *part = parts > 1 ? many.data() : &one;
+            split_run(b, e, parts, [&](int t, size_t pb, size_t pe) {
+                Bounds &B = part[(size_t)t];
+                box_reset(B.lo, B.hi); box_reset(B.clo, B.chi);
+                for (size_t i = pb; i < pe; ++i) {
+                    box_grow(B.lo, B.hi, prims[i].lo, prims[i].hi);
+                    const float c[3] = {cen(prims[i], 0), cen(prims[i], 1), cen(prims[i], 2)};
+                    box_grow(B.clo, B.chi, c, c);
+                }
+            });
+            box_reset(N.lo, N.hi); box_reset(clo, chi);
+            for (int t = 0; t < parts; ++t) { box_grow(N.lo, N.hi, part[t].lo, part[t].hi); box_grow(clo, chi, part[t].clo, part[t].chi); }
+        }
         note_depth(depth);
-        auto make_leaf = [&]() { N.left = N.right = -1; N.first = (uint32_t)b; N.count = (uint32_t)n; };
+        auto make_leaf = [&]() { N.left = N.right = -1; N.first = (uint32_t)b; N.count = (uint32_t)n; N.inner = 0; };
         if (n <= 1) { make_leaf(); return; }
 
         // depth guard: the inner nodes below this one may use at most `room` more levels
@@ -86,39 +135,69 @@ struct Builder {
         float best_cost = std::numeric_limits<float>::infinity();
         float parent_area = half_area(N.lo, N.hi);
         if (!force_median) {
+            // one pass over the primitives bins all three axes
+            bool use[3]; float scale3[3];
             for (int ax = 0; ax < 3; ++ax) {
                 float ext = chi[ax] - clo[ax];
-                if (!(ext > 0.0f)) continue;
-                float scale = (float)kBins / ext;
-                uint32_t cnt[kMaxBins] = {0};
-                float blo[kMaxBins][3], bhi[kMaxBins][3];
-                for (int k = 0; k < kBins; ++k) box_reset(blo[k], bhi[k]);
-                for (size_t i = b; i < e; ++i) {
-                    int k = (int)((prims[i].c[ax] - clo[ax]) * scale);
-                    k = k < 0 ? 0 : (k >= kBins ? kBins - 1 : k);
-                    cnt[k]++;
-                    box_grow(blo[k], bhi[k], prims[i].lo, prims[i].hi);
+                use[ax] = ext > 0.0f;
+                scale3[ax] = use[ax] ? (float)kBins / ext : 0.0f;
+            }
+            // a thread's own bins stay clean between nodes (only the bins a node filled are reset after it): most nodes
+            // hold a handful of primitives, and resetting and sweeping all 3 x kBins bins for them was most of the build
+            static thread_local Bins tl_bins;
+            static thread_local bool tl_clean = false;
+            if (!tl_clean) { tl_bins.reset(kMaxBins); tl_clean = true; }
+            std::vector<Bins> many;
+            if (parts > 1) { many.resize((size_t)parts - 1); for (Bins &B : many) B.reset(kBins); }
+            Bins &A = tl_bins;
+            split_run(b, e, parts, [&](int t, size_t pb, size_t pe) {
+                Bins &B = t == 0 ? A : many[(size_t)t - 1];
+                for (size_t i = pb; i < pe; ++i) {
+                    const Prim &P = prims[i];
+                    for (int ax = 0; ax < 3; ++ax) {
+                        if (!use[ax]) continue;
+                        int k = (int)((cen(P, ax) - clo[ax]) * scale3[ax]);
+                        k = k < 0 ? 0 : (k >= kBins ? kBins - 1 : k);
+                        B.cnt[ax][k]++;
+                        box_grow(B.blo[ax][k], B.bhi[ax][k], P.lo, P.hi);
+                    }
                 }
-                float ra[kMaxBins]; uint32_t rc[kMaxBins];
+            });
+            for (const Bins &B : many)
+                for (int ax = 0; ax < 3; ++ax)
+                    for (int k = 0; k < kBins; ++k) {
+                        A.cnt[ax][k] += B.cnt[ax][k];
+                        box_grow(A.blo[ax][k], A.bhi[ax][k], B.blo[ax][k], B.bhi[ax][k]);
+                    }
+            for (int ax = 0; ax < 3; ++ax) {
+                if (!use[ax]) continue;
+                uint32_t *cnt = A.cnt[ax];
+                float (*blo)[3] = A.blo[ax], (*bhi)[3] = A.bhi[ax];
+                // only the non-empty bins matter: a split after an empty bin costs exactly what the split after the
+                // last non-empty bin before it costs, and the first of equal costs is the one kept
+                int nz[kMaxBins], m = 0;
+                for (int k = 0; k < kBins; ++k) if (cnt[k]) nz[m++] = k;
+                float ra[kMaxBins]; uint32_t rc[kMaxBins];     // area / count of non-empty bins j .. m-1
                 float lo[3], hi[3];
                 box_reset(lo, hi);
                 uint32_t c = 0;
-                for (int k = kBins - 1; k > 0; --k) {
-                    if (cnt[k]) box_grow(lo, hi, blo[k], bhi[k]);
-                    c += cnt[k];
-                    rc[k] = c; ra[k] = c ? half_area(lo, hi) : 0.0f;
+                for (int j = m - 1; j > 0; --j) {
+                    box_grow(lo, hi, blo[nz[j]], bhi[nz[j]]);
+                    c += cnt[nz[j]];
+                    rc[j] = c; ra[j] = half_area(lo, hi);
                 }
                 box_reset(lo, hi);
                 c = 0;
-                for (int k = 0; k < kBins - 1; ++k) {
-                    if (cnt[k]) box_grow(lo, hi, blo[k], bhi[k]);
-                    c += cnt[k];
-                    if (c == 0 || rc[k + 1] == 0) continue;
-                    float cost = half_area(lo, hi) * (float)c + ra[k + 1] * (float)rc[k + 1];
-                    if (cost < best_cost) { best_cost = cost; best_axis = ax; best_bin = k; }
+                for (int j = 0; j + 1 < m; ++j) {
+                    box_grow(lo, hi, blo[nz[j]], bhi[nz[j]]);
+                    c += cnt[nz[j]];
+                    float cost = half_area(lo, hi) * (float)c + ra[j + 1] * (float)rc[j + 1];
+                    if (cost < best_cost) { best_cost = cost; best_axis = ax; best_bin = nz[j]; }
                 }
+                for (int j = 0; j < m; ++j) { cnt[nz[j]] = 0; box_reset(blo[nz[j]], bhi[nz[j]]); }      // clean again
             }
         }
+        if (extra) free_threads.fetch_add(extra);      // the subtrees below may take them
         size_t mid = b;
         if (best_axis >= 0) {
             float split_cost = kCostNode + kCostTri * best_cost / (parent_area > 0.0f ? parent_area : 1.0f);
@@ -129,7 +208,7 @@ struct Builder {
             float c0 = clo[best_axis];
             int ax = best_axis, bin = best_bin;
             Prim *p = std::partition(prims.data() + b, prims.data() + e, [=](const Prim &P) {
-                int k = (int)((P.c[ax] - c0) * scale);
+                int k = (int)((cen(P, ax) - c0) * scale);
                 k = k < 0 ? 0 : (k >= kBins ? kBins - 1 : k);
                 return k <= bin;
             });
@@ -144,22 +223,24 @@ struct Builder {
             mid = b + n / 2;
             std::nth_element(prims.begin() + b, prims.begin() + mid, prims.begin() + e,
                              [ax](const Prim &A, const Prim &B) {
-                                 return A.c[ax] < B.c[ax] || (A.c[ax] == B.c[ax] && A.seq < B.seq);
+                                 const float ca = cen(A, ax), cb = cen(B, ax);
+                                 return ca < cb || (ca == cb && A.seq < B.seq);
                              });
         }
         uint32_t l = alloc(), r = alloc();
         N.left = (int32_t)l; N.right = (int32_t)r; N.first = 0; N.count = 0;
         size_t nl = mid - b;
         if (std::min(nl, n - nl) >= kSpawnMin && free_threads.fetch_sub(1) > 0) {
-            std::thread t([this, l, b, mid, depth]() { build(l, b, mid, depth + 1); });
+            // the helper hands its token back itself, as soon as it is done: joined only after this thread's own half
+            std::thread t([this, l, b, mid, depth]() { build(l, b, mid, depth + 1); free_threads.fetch_add(1); });
             build(r, mid, e, depth + 1);
             t.join();
-            free_threads.fetch_add(1);
         } else {
             if (std::min(nl, n - nl) >= kSpawnMin) free_threads.fetch_add(1); // undo failed grab
             build(l, b, mid, depth + 1);
             build(r, mid, e, depth + 1);
         }
+        nodes[ni].inner = 1u + nodes[l].inner + nodes[r].inner;
     }
 };
 
@@ -178,42 +259,53 @@ void rt_bvh_build(const rt_triangle *tris, size_t n_tris, const rt_mesh_info *me
     if (const char *e = std::getenv("RT_TUNE_COST_TRI")) kCostTri = (float)std::atof(e);
     if (const char *e = std::getenv("RT_TUNE_BINS")) { int v = std::atoi(e); if (v >= 4 && v <= kMaxBins) kBins = v; }
     if (const char *e = std::getenv("RT_TUNE_MAX_LEAF")) { int v = std::atoi(e); if (v >= 1 && v <= 8) kMaxLeaf = (uint32_t)v; }
-    Builder B;
-    size_t total = 0;
-    for (size_t m = 0; m < n_meshes; ++m) total += meshes[m].tri_count;
-    B.prims.reserve(total + n_spheres);
-    uint32_t seq = 0;
-    for (size_t m = 0; m < n_meshes; ++m) {
-        for (uint32_t j = meshes[m].first_tri; j < meshes[m].first_tri + meshes[m].tri_count; ++j, ++seq) {
-            const float *a = verts[tris[j].indices[0]].pos;
-            const float *b = verts[tris[j].indices[1]].pos;
-            const float *c = verts[tris[j].indices[2]].pos;
-            Prim P;
-            bool finite = true;
-            float amax = 0.0f;
-            for (int k = 0; k < 3; ++k) {
-                finite = finite && std::isfinite(a[k]) && std::isfinite(b[k]) && std::isfinite(c[k]);
-                P.lo[k] = std::min(a[k], std::min(b[k], c[k]));
-                P.hi[k] = std::max(a[k], std::max(b[k], c[k]));
-                amax = std::max(amax, std::max(std::fabs(P.lo[k]), std::fabs(P.hi[k])));
-            }
-            // A triangle with a NaN/inf vertex can never pass ray_triangle's comparisons in a
-            // way a box could bound; it is left out of the tree.
-            if (!finite) { out->dropped++; continue; }
-            // pad so that rounding in the slab test can never cull a triangle the exact f32
-            // ray_triangle arithmetic accepts (DESIGN.md "Conservative culling")
-            float pad = 1e-5f * amax + 1e-30f;
-            for (int k = 0; k < 3; ++k) {
-                P.lo[k] -= pad; P.hi[k] += pad;
-                P.c[k] = 0.5f * P.lo[k] + 0.5f * P.hi[k];
-            }
-            P.seq = seq; P.tri = j; P.mesh = (uint32_t)m;
-            B.prims.push_back(P);
-        }
+    if (n_threads <= 0) {
+        n_threads = (int)std::thread::hardware_concurrency();
+        if (n_threads > 16) n_threads = 16;
+        if (n_threads < 1) n_threads = 1;
     }
-    for (size_t i = 0; i < n_spheres; ++i, ++seq) {
+    Builder B;
+    // primitives in the reference's loop order (mesh by mesh, then the spheres): seq = position in that order
+    std::vector<size_t> mesh_off(n_meshes + 1, 0);
+    for (size_t m = 0; m < n_meshes; ++m) mesh_off[m + 1] = mesh_off[m] + meshes[m].tri_count;
+    const size_t total = mesh_off[n_meshes];
+    B.prims.resize(total + n_spheres);
+    std::vector<uint8_t> keep;                    // only allocated if something has to be dropped
+    std::atomic<size_t> dropped{0};
+    std::atomic<bool> any_drop{false};
+    auto bake_meshes = [&](int, size_t mb, size_t me) {
+        size_t local_drop = 0;
+        for (size_t m = mb; m < me; ++m) {
+            size_t seq = mesh_off[m];
+            for (uint32_t j = meshes[m].first_tri; j < meshes[m].first_tri + meshes[m].tri_count; ++j, ++seq) {
+                const float *a = verts[tris[j].indices[0]].pos;
+                const float *b = verts[tris[j].indices[1]].pos;
+                const float *c = verts[tris[j].indices[2]].pos;
+                Prim &P = B.prims[seq];
+                bool finite = true;
+                float amax = 0.0f;
+                for (int k = 0; k < 3; ++k) {
+                    finite = finite && std::isfinite(a[k]) && std::isfinite(b[k]) && std::isfinite(c[k]);
+                    P.lo[k] = std::min(a[k], std::min(b[k], c[k]));
+                    P.hi[k] = std::max(a[k], std::max(b[k], c[k]));
+                    amax = std::max(amax, std::max(std::fabs(P.lo[k]), std::fabs(P.hi[k])));
+                }
+                // pad so that rounding in the slab test can never cull a triangle the exact f32
+                // ray_triangle arithmetic accepts (DESIGN.md "Conservative culling")
+                float pad = 1e-5f * amax + 1e-30f;
+                for (int k = 0; k < 3; ++k) { P.lo[k] -= pad; P.hi[k] += pad; }
+                P.seq = (uint32_t)seq; P.tri = j;
+                // A triangle with a NaN/inf vertex can never pass ray_triangle's comparisons in a
+                // way a box could bound; it is left out of the tree (marked here, removed below).
+                if (!finite) { P.tri = kDroppedTri; ++local_drop; }
+            }
+        }
+        if (local_drop) { dropped += local_drop; any_drop = true; }
+    };
+    Builder::split_run(0, n_meshes, total >= ((size_t)1 << 16) ? n_threads : 1, bake_meshes);
+    for (size_t i = 0; i < n_spheres; ++i) {
         const rt_sphere &sp = spheres[i];
-        Prim P;
+        Prim &P = B.prims[total + i];
         bool finite = std::isfinite(sp.radius);
         float amax = 0.0f;
         float r = std::fabs(sp.radius);
@@ -222,55 +314,57 @@ void rt_bvh_build(const rt_triangle *tris, size_t n_tris, const rt_mesh_info *me
             P.lo[k] = sp.center[k] - r; P.hi[k] = sp.center[k] + r;
             amax = std::max(amax, std::max(std::fabs(P.lo[k]), std::fabs(P.hi[k])));
         }
-        if (!finite) { out->dropped++; continue; }
         // same padding rule as triangles, plus the rounding of centre +/- radius itself
         float pad = 2e-5f * amax + 1e-30f;
-        for (int k = 0; k < 3; ++k) {
-            P.lo[k] -= pad; P.hi[k] += pad;
-            P.c[k] = 0.5f * P.lo[k] + 0.5f * P.hi[k];
-        }
-        P.seq = seq; P.tri = (uint32_t)(n_tris + i); P.mesh = RT_REC_SPHERE;
-        B.prims.push_back(P);
+        for (int k = 0; k < 3; ++k) { P.lo[k] -= pad; P.hi[k] += pad; }
+        P.seq = (uint32_t)(total + i); P.tri = (uint32_t)(n_tris + i);
+        if (!finite) { P.tri = kDroppedTri; dropped += 1; any_drop = true; }
+    }
+    if (any_drop.load()) {          // rare: compact, order kept
+        size_t w = 0;
+        for (size_t i = 0; i < B.prims.size(); ++i) if (B.prims[i].tri != kDroppedTri) B.prims[w++] = B.prims[i];
+        B.prims.resize(w);
+        out->dropped = (uint32_t)dropped.load();
     }
     size_t n = B.prims.size();
     if (n == 0) { out->build_ms = 0.0; return; }
 
-    if (n_threads <= 0) {
-        n_threads = (int)std::thread::hardware_concurrency();
-        if (n_threads > 16) n_threads = 16;
-        if (n_threads < 1) n_threads = 1;
-    }
     B.free_threads = n_threads - 1;
-    B.nodes.resize(2 * n + 1);
+    B.nodes.reset(new TmpNode[2 * n + 1]);
     uint32_t root = B.alloc();
     B.build(root, 0, n, 0);
 
     // leaf records in prim order
     out->recs.resize(n);
-    for (size_t i = 0; i < n; ++i) {
-        const Prim &P = B.prims[i];
-        if (P.mesh == RT_REC_SPHERE) {
-            const rt_sphere &sp = spheres[P.tri - n_tris];
+    Builder::split_run(0, n, n >= ((size_t)1 << 16) ? n_threads : 1, [&](int, size_t ib, size_t ie) {
+        for (size_t i = ib; i < ie; ++i) {
+            const Prim &P = B.prims[i];
             RtTriRecord &R = out->recs[i];
-            std::memset(&R, 0, sizeof R);
-            R.a[0] = sp.center[0]; R.a[1] = sp.center[1]; R.a[2] = sp.center[2];
-            R.abx = sp.radius;
-            R.tri = P.tri; R.mesh = RT_REC_SPHERE; R.seq = P.seq;
-            continue;
+            if (P.seq >= total) {                 // the spheres come after every mesh in loop order
+                const rt_sphere &sp = spheres[P.tri - n_tris];
+                std::memset(&R, 0, sizeof R);
+                R.a[0] = sp.center[0]; R.a[1] = sp.center[1]; R.a[2] = sp.center[2];
+                R.abx = sp.radius;
+                R.tri = P.tri; R.mesh = RT_REC_SPHERE; R.seq = P.seq;
+                continue;
+            }
+            const float *a = verts[tris[P.tri].indices[0]].pos;
+            const float *b = verts[tris[P.tri].indices[1]].pos;
+            const float *c = verts[tris[P.tri].indices[2]].pos;
+            R.a[0] = a[0]; R.a[1] = a[1]; R.a[2] = a[2];
+            // edge_ab = b.pos - a.pos, edge_ac = c.pos - a.pos: plain f32 subtractions, the same
+            // values ray_tracing.wgsl:122-123 computes per test
+            R.abx = b[0] - a[0]; R.aby = b[1] - a[1]; R.abz = b[2] - a[2];
+            R.acx = c[0] - a[0]; R.acy = c[1] - a[1]; R.acz = c[2] - a[2];
+            // its mesh: the one whose run of the loop order holds seq
+            R.tri = P.tri; R.seq = P.seq;
+            R.mesh = (uint32_t)(std::upper_bound(mesh_off.begin(), mesh_off.end(), (size_t)P.seq) - mesh_off.begin() - 1);
         }
-        const float *a = verts[tris[P.tri].indices[0]].pos;
-        const float *b = verts[tris[P.tri].indices[1]].pos;
-        const float *c = verts[tris[P.tri].indices[2]].pos;
-        RtTriRecord &R = out->recs[i];
-        R.a[0] = a[0]; R.a[1] = a[1]; R.a[2] = a[2];
-        // edge_ab = b.pos - a.pos, edge_ac = c.pos - a.pos: plain f32 subtractions, the same
-        // values ray_tracing.wgsl:122-123 computes per test
-        R.abx = b[0] - a[0]; R.aby = b[1] - a[1]; R.abz = b[2] - a[2];
-        R.acx = c[0] - a[0]; R.acy = c[1] - a[1]; R.acz = c[2] - a[2];
-        R.tri = P.tri; R.mesh = P.mesh; R.seq = P.seq;
-    }
+    });
 
-    // flatten to the 64-B two-child layout, depth-first so a subtree is contiguous
+    // flatten to the 64-B two-child layout: a node's inner children sit next to each other, then everything below
+    // the second child, then everything below the first (the order a stack that pushes child 0, then child 1 gives).
+    // With the subtree sizes from the build every node's place is known in advance, so subtrees flatten in parallel.
     const float qnan = std::numeric_limits<float>::quiet_NaN();
     const TmpNode &R = B.nodes[root];
     double root_area = half_area(R.lo, R.hi);
@@ -287,37 +381,56 @@ void rt_bvh_build(const rt_triangle *tris, size_t n_tris, const rt_mesh_info *me
         max_leaf = R.count;
         sah = kCostNode + kCostTri * R.count;
     } else {
-        out->nodes.reserve(B.next_node.load() / 2 + 1);
-        struct Item { uint32_t tmp; uint32_t out; };
-        std::vector<Item> stack;
-        out->nodes.emplace_back();
-        stack.push_back({root, 0});
-        while (!stack.empty()) {
-            Item it = stack.back(); stack.pop_back();
-            const TmpNode &T = B.nodes[it.tmp];
-            sah += kCostNode * half_area(T.lo, T.hi) / root_area;
-            RtBvhNode node;
-            std::memset(&node, 0, sizeof node);
-            const TmpNode *ch[2] = {&B.nodes[T.left], &B.nodes[T.right]};
-            int32_t code[2];
-            for (int c = 0; c < 2; ++c) {
-                if (ch[c]->left < 0) {
-                    code[c] = leaf_code(ch[c]->first, ch[c]->count);
-                    max_leaf = std::max(max_leaf, ch[c]->count);
-                    sah += kCostTri * ch[c]->count * half_area(ch[c]->lo, ch[c]->hi) / root_area;
-                } else {
-                    uint32_t idx = (uint32_t)out->nodes.size();
-                    out->nodes.emplace_back();
-                    code[c] = (int32_t)idx;
-                    stack.push_back({(uint32_t)(c == 0 ? T.left : T.right), idx});
+        out->nodes.resize(R.inner);
+        struct Item { uint32_t tmp, out, base; };      // base: where this node's inner children go
+        B.free_threads = n_threads - 1;
+        std::atomic<uint32_t> max_leaf_all{0};
+        std::function<void(Item)> flatten = [&](Item first) {
+            std::vector<Item> stack{first};
+            std::vector<std::thread> helpers;
+            uint32_t ml = 0;
+            while (!stack.empty()) {
+                Item it = stack.back(); stack.pop_back();
+                const TmpNode &T = B.nodes[it.tmp];
+                const TmpNode *ch[2] = {&B.nodes[T.left], &B.nodes[T.right]};
+                RtBvhNode node;
+                std::memset(&node, 0, sizeof node);
+                int32_t code[2];
+                uint32_t next = it.base;
+                for (int c = 0; c < 2; ++c) {
+                    if (ch[c]->left < 0) { code[c] = leaf_code(ch[c]->first, ch[c]->count); ml = std::max(ml, ch[c]->count); }
+                    else code[c] = (int32_t)next++;
                 }
+                for (int k = 0; k < 3; ++k) {
+                    node.lo0[k] = ch[0]->lo[k]; node.hi0[k] = ch[0]->hi[k];
+                    node.lo1[k] = ch[1]->lo[k]; node.hi1[k] = ch[1]->hi[k];
+                }
+                node.child0 = code[0]; node.child1 = code[1];
+                out->nodes[it.out] = node;
+                // below child 1 first, then below child 0
+                uint32_t base1 = next, base0 = next + (ch[1]->left < 0 ? 0u : ch[1]->inner - 1u);
+                if (ch[0]->left >= 0) {
+                    Item i0{(uint32_t)T.left, (uint32_t)code[0], base0};
+                    if (ch[0]->inner >= (1u << 14) && B.free_threads.fetch_sub(1) > 0)
+                        helpers.emplace_back([&flatten, &B, i0]() { flatten(i0); B.free_threads.fetch_add(1); });
+                    else { if (ch[0]->inner >= (1u << 14)) B.free_threads.fetch_add(1); stack.push_back(i0); }
+                }
+                if (ch[1]->left >= 0) stack.push_back({(uint32_t)T.right, (uint32_t)code[1], base1});
             }
-            for (int k = 0; k < 3; ++k) {
-                node.lo0[k] = ch[0]->lo[k]; node.hi0[k] = ch[0]->hi[k];
-                node.lo1[k] = ch[1]->lo[k]; node.hi1[k] = ch[1]->hi[k];
-            }
-            node.child0 = code[0]; node.child1 = code[1];
-            out->nodes[it.out] = node;
+            for (auto &t : helpers) t.join();
+            uint32_t cur = max_leaf_all.load();
+            while (ml > cur && !max_leaf_all.compare_exchange_weak(cur, ml)) {}
+        };
+        flatten({root, 0u, 1u});
+        max_leaf = max_leaf_all.load();
+        // SAH cost of the tree, summed in storage order
+        for (const RtBvhNode &N : out->nodes) {
+            float lo[3], hi[3];
+            box_reset(lo, hi);
+            box_grow(lo, hi, N.lo0, N.hi0); box_grow(lo, hi, N.lo1, N.hi1);
+            sah += kCostNode * half_area(lo, hi) / root_area;
+            if (N.child0 < 0) sah += kCostTri * ((((uint32_t)~N.child0) & 7u) + 1u) * half_area(N.lo0, N.hi0) / root_area;
+            if (N.child1 < 0) sah += kCostTri * ((((uint32_t)~N.child1) & 7u) + 1u) * half_area(N.lo1, N.hi1) / root_area;
         }
     }
     out->max_depth = B.max_depth.load();
@@ -446,9 +559,9 @@ void rt_bvh_widen(const RtBvhBuildResult &bvh, RtWideTree *out) {
                 stack.push_back({(uint32_t)s[k].code, idx, it.depth + 1});
             } else W.child[k] = s[k].code;
         }
-        rt_wide_quantise(bvh.nodes.data(), S, W);
         out->nodes[it.wide] = W; out->src[it.wide] = S;
     }
+    rt_wide_requantise(bvh, out);       // the boxes, on all threads (the walk above only fixes topology and order)
     // worst-case stack use: with n children hit, n-1 wait on the stack while the first subtree is walked, n-2
     // during the second, ...; the worst order visits the neediest subtree first
     std::vector<uint32_t> need(out->nodes.size(), 0);

@@ -419,3 +419,18 @@ def test_cpu_walk_of_the_exported_bvh_finds_the_oracles_hits():
                             best = (h["t"], int(recs["seq"][k]), int(recs["tri"][k]))
             assert best[2] == prim_o[py, px]
             assert (best[0] if best[2] != 0xFFFFFFFF else 0.0) == t_o[py, px]
+
+
+def test_bvh_is_the_same_tree_whatever_the_thread_count():
+    """The builder's threads take whole subtrees and, in nodes of >= 2^18 primitives, shares of the passes over the
+    primitives (bounds, binning): minima, maxima and counts do not depend on how a run is cut up, so binary tree, leaf
+    records and wide tree must be identical, byte for byte, for any thread count."""
+    scene = soup_app(420, 0x5EED0009, 64, 64).prepare_meshinfo()          # 302,400 triangles: the root takes the parallel passes
+    assert len(scene.triangles) > (1 << 18)
+    ref = None
+    for threads in (1, 3, 8):
+        info, nodes, recs, wn, ws, need = rt.host_bvh_build(scene, threads=threads, wide=True)
+        cur = (nodes.tobytes(), recs.tobytes(), wn.tobytes(), ws.tobytes(), need, info.max_depth, info.max_leaf)
+        if ref is None:
+            ref = cur
+        assert cur == ref, threads

@@ -8,6 +8,7 @@
 #include <cstring>
 #include <map>
 #include <stdexcept>
+#include <thread>
 #include <tuple>
 
 namespace ray_tracing {
@@ -283,20 +284,35 @@ void prepare_meshinfo(World &world) {
     for (size_t i = 0; same && i < world.entities.size(); ++i)
         same = world.entities[i].mesh == world.baked[i].mesh && world.entities[i].material == world.baked[i].material;
     if (same) {
-        bool changed = false;
+        std::vector<uint32_t> moved;
+        size_t moved_vertices = 0;
         for (size_t i = 0; i < world.entities.size(); ++i) {
             const Entity &e = world.entities[i];
-            World::Baked &b = world.baked[i];
+            const World::Baked &b = world.baked[i];
             if (b.mesh_info < 0) { world.log += "Mesh missing attribute\n"; continue; }
             if (std::memcmp(&e.transform, &b.transform, sizeof e.transform) == 0 &&
                 std::memcmp(&e.aabb.half_extents, &b.aabb.half_extents, sizeof e.aabb.half_extents) == 0) continue;
-            MeshInfo &mi = world.ray_tracing_info.meshes[b.mesh_info];
-            bake_entity(e, world.meshes[e.mesh], world.ray_tracing_info.vertices.data() + b.first_vertex, b.n_vertices, mi.aabb_min, mi.aabb_max);
-            b.transform = e.transform; b.aabb = e.aabb;
-            world.moved_meshes.push_back((uint32_t)b.mesh_info);
-            changed = true;
+            moved.push_back((uint32_t)i);
+            moved_vertices += b.n_vertices;
         }
-        if (changed) world.info_generation++;
+        auto rebake = [&](size_t mb, size_t me) {          // entities own disjoint runs of the arrays
+            for (size_t q = mb; q < me; ++q) {
+                const Entity &e = world.entities[moved[q]];
+                World::Baked &b = world.baked[moved[q]];
+                MeshInfo &mi = world.ray_tracing_info.meshes[b.mesh_info];
+                bake_entity(e, world.meshes[e.mesh], world.ray_tracing_info.vertices.data() + b.first_vertex, b.n_vertices, mi.aabb_min, mi.aabb_max);
+                b.transform = e.transform; b.aabb = e.aabb;
+            }
+        };
+        int threads = (int)std::min<size_t>(std::min<size_t>(moved.size(), moved_vertices >> 15), std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency())));
+        if (threads <= 1) rebake(0, moved.size());
+        else {                                             // many entities moved at once: their runs are baked side by side
+            std::vector<std::thread> th;
+            for (int t = 0; t < threads; ++t) th.emplace_back(rebake, moved.size() * (size_t)t / threads, moved.size() * (size_t)(t + 1) / threads);
+            for (auto &t : th) t.join();
+        }
+        for (uint32_t i : moved) world.moved_meshes.push_back((uint32_t)world.baked[i].mesh_info);
+        if (!moved.empty()) world.info_generation++;
         return;
     }
     RayTracingInfo info = world.ray_tracing_info;   // `ray_tracing_info.clone()` keeps `count` (:112)

@@ -155,6 +155,13 @@ def test_prepare_meshinfo_rebakes_only_what_moved_and_leaves_the_full_result():
         assert _same(s, orc.prepare_meshinfo(app.entities())), step
         assert app.log().count("Mesh missing attribute") == n_log + 1          # the skipped entity is reported every pass
     assert _same(app.prepare_meshinfo(), s)                                      # nothing moved: nothing changes
+    # many entities at once (their runs are then re-baked on several threads)
+    big = soup_app(60, 0x5EED0004, 64, 64)
+    big.prepare_meshinfo()
+    for k, e in enumerate(big.entities()):
+        a = 0.1 * (k + 1)
+        big.set_transform(k, e["scale"], (0.0, float(np.sin(a)), 0.0, float(np.cos(a))), e["translation"] + np.float32(0.25))
+    assert _same(big.prepare_meshinfo(), orc.prepare_meshinfo(big.entities()))
     # a new asset, or a world cleared and refilled with as many entities: a full pass again
     app.spawn(app.add_cuboid(2, 2, 2), mats[1], translation=(0, 5, 0))
     assert _same(app.prepare_meshinfo(), orc.prepare_meshinfo(app.entities()))

@@ -7,7 +7,8 @@ sys.path[:0] = [_ROOT]
 import numpy as np, ray_tracing_amd as rt
 
 def run(name, app, frames=200, entity=None):
-    ent = app.entities()[entity] if entity is not None else None
+    all_ents = app.entities() if entity == "all" else None
+    ent = app.entities()[entity] if isinstance(entity, int) else None
     app.camera_set_target(1920, 1080)
     app.finish(0)
     assert app.update(flags=rt.FLAG_SHADOW) == rt.RT_OK           # first frame: upload + build
@@ -18,7 +19,10 @@ def run(name, app, frames=200, entity=None):
     ctx.read_hit_t(); t_static = (time.perf_counter() - t_static) / frames
     t0 = time.perf_counter()
     for f in range(frames):
-        if entity is None: app.rotate_tagged(1.0 / 60.0)
+        if entity == "all":
+            a = 0.5 * (f + 1) / 60.0
+            for k, e in enumerate(all_ents): app.set_transform(k, e["scale"], (0.0, float(np.sin(a)), 0.0, float(np.cos(a))), e["translation"])
+        elif entity is None: app.rotate_tagged(1.0 / 60.0)
         else:
             a = 0.5 * (f + 1) / 60.0
             app.set_transform(entity, ent["scale"], (0.0, float(np.sin(a)), 0.0, float(np.cos(a))), ent["translation"])
@@ -31,3 +35,5 @@ def run(name, app, frames=200, entity=None):
 app = rt.App(); app.spawn_default_scene(); run("default scene, 2,894 triangles", app)
 app = rt.App(); app.spawn_sphere_field(2000, 0x5EED0002, 5); app.camera_frame_scene(1.0)
 run("sphere field, 1.44 M triangles, sphere 7 spinning", app, frames=50, entity=7)
+app = rt.App(); app.spawn_sphere_field(2000, 0x5EED0002, 5); app.camera_frame_scene(1.0)
+run("sphere field, 1.44 M triangles, every entity spinning (Python sets 2,001 transforms per frame)", app, frames=20, entity="all")

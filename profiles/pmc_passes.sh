@@ -4,7 +4,7 @@ set -u
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 OUT=gpurun_out/pmc_$1
 mkdir -p $OUT
-CMD="python bench.py --steps 5 --warmup 1 --no-cpu-baseline ${BENCH_ARGS:-}"
+CMD="python bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-pipelined ${BENCH_ARGS:-}"
 run() { name=$1; shift; timeout -s KILL 150 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/$name -- $CMD > $OUT/$name.log 2>&1 || { echo "pass $name failed"; tail -5 $OUT/$name.log; exit 1; }; echo "pass $name ok"; }
 run sq1 SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY
 run sq2 SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_SMEM SQ_THREAD_CYCLES_VALU SQ_LDS_BANK_CONFLICT SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VMEM

@@ -89,3 +89,25 @@ def test_counters_equal_the_oracle_tree_walk(name):
                 assert c.rays_primary + c.rays_shadow == rays_o
                 assert (c.node_visits, c.tri_tests, c.mesh_aabb_tests) == (nv, nt, nc), (name, tree_flag, extra, kernel)
     ctx.close()
+
+
+def test_two_contexts_on_one_gpu_render_concurrently():
+    """Two contexts = two streams and two sets of frame buffers: frames submitted alternately overlap on the device (the
+    way to keep two frames in flight); each context must still deliver its own frame, bit for bit."""
+    app = default_app(320, 180)
+    scene = app.prepare_meshinfo()
+    m, p = app.camera_view()
+    app2 = default_app(320, 180)
+    app2.rotate_tagged(0.4)                        # the second context renders a different pose of the cube
+    scene2 = app2.prepare_meshinfo()
+    ref = [orc.render_primary(oracle_scene(s), oracle_view(app), orc.FLAG_SHADOW) for s in (scene, scene2)]
+    with rt.Context(0) as a, rt.Context(0) as b:
+        for ctx, s in ((a, scene), (b, scene2)):
+            ctx.upload_scene(s)
+            ctx.set_view(m, p, 320, 180)
+        for _ in range(20):                        # no synchronisation between the submissions
+            assert a.render(flags=rt.FLAG_SHADOW) == rt.RT_OK
+            assert b.render(flags=rt.FLAG_SHADOW) == rt.RT_OK
+        for ctx, (rgba_o, prim_o, t_o, _) in ((a, ref[0]), (b, ref[1])):
+            assert bitwise_equal(ctx.read_prim_ids(), prim_o) and bitwise_equal(ctx.read_radiance(), rgba_o)
+        assert not bitwise_equal(a.read_prim_ids(), b.read_prim_ids())

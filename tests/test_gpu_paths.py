@@ -760,3 +760,46 @@ def test_deep_tree_uses_the_private_part_of_the_stack():
             assert ctx.render(flags=extra | rt.FLAG_COUNTERS) == rt.RT_OK
             assert (ctx.read_prim_ids() == 0xFFFFFFFF).all()
             assert ctx.counters().tri_tests > 10_000                         # they walked into the stack, leaf after leaf
+
+
+@pytest.mark.parametrize("list_max", ["16384", "0"])
+def test_update_vertex_range_random_sequences(list_max, monkeypatch):
+    """A sequence of random ranged updates (runs of 1-6 meshes, random moves, some back to where they were) on one context
+    against full updates on another: after every step the binary tree, the records and the wide tree must be identical."""
+    monkeypatch.setenv("RT_TUNE_REFIT_LIST_MAX", list_max)
+    app = soup_app(40, 0x5EED0007, 96, 54, subdivisions=2)
+    app.camera_frame_scene(1.0)
+    scene = app.prepare_meshinfo()
+    cur = rt.Scene(scene.triangles, scene.meshes.copy(), scene.vertices.copy(), scene.materials)
+    rng = np.random.default_rng(23)
+    spans = []
+    for mi in scene.meshes:
+        vs = scene.triangles["indices"][mi["first_tri"]:mi["first_tri"] + mi["tri_count"]]
+        spans.append((int(vs.min()), int(vs.max())))
+    m, p = app.camera_view()
+    with rt.Context(0) as full, rt.Context(0) as part:
+        for ctx in (full, part):
+            ctx.upload_scene(scene)
+            ctx.set_view(m, p, 96, 54)
+        for step in range(12):
+            m0 = int(rng.integers(0, 40))
+            m1 = min(40, m0 + int(rng.integers(1, 7)))
+            for k in range(m0, m1):
+                lo, hi = spans[k]
+                if step % 4 == 3:                       # back to the uploaded pose
+                    cur.vertices[lo:hi + 1] = scene.vertices[lo:hi + 1]
+                    cur.meshes[k] = scene.meshes[k]
+                else:
+                    shift = rng.uniform(-3, 3, 3).astype(np.float32)
+                    cur.vertices["pos"][lo:hi + 1] += shift
+                    cur.meshes["aabb_min"][k] += shift
+                    cur.meshes["aabb_max"][k] += shift
+            v0, v1 = spans[m0][0], spans[m1 - 1][1]
+            part.update_vertex_range(cur, v0, v1 - v0 + 1, m0, m1 - m0)
+            full.update_vertices(cur)
+            (nf, rf), (np_, rp) = full.read_bvh(), part.read_bvh()
+            assert bitwise_equal(np_, nf) and bitwise_equal(rp, rf), step
+            assert bitwise_equal(part.read_bvh_wide(), full.read_bvh_wide()), step
+        part.render(flags=rt.FLAG_SHADOW)
+        rgba_o, prim_o, t_o, _ = orc.render_primary(oracle_scene(cur), oracle_view(app), orc.FLAG_SHADOW)
+        assert bitwise_equal(part.read_prim_ids(), prim_o) and bitwise_equal(part.read_radiance(), rgba_o)

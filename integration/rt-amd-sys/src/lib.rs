@@ -51,7 +51,41 @@ pub const RT_FLAG_WAVE_TRAVERSAL: u32 = 0x0080;
 pub const RT_FLAG_STATIC_GRID: u32 = 0x0100;
 pub const RT_FLAG_BINARY_TREE: u32 = 0x0200;
 
+/// Counters of the last `rt_render` (include/rt_amd.h `rt_counters`).
+#[repr(C)]
+#[derive(Clone, Copy, Default)]
+pub struct rt_counters {
+    pub rays_primary: u64, pub rays_shadow: u64, pub rays_bounce: u64,
+    pub node_visits: u64, pub tri_tests: u64, pub mesh_aabb_tests: u64,
+    pub kernel_ms: f64, pub kernel_launches: u32, pub _pad: u32,
+    pub wave_node_iters: u64, pub wave_tri_iters: u64, pub wave_alive_lanes: u64,
+}
+/// What the library built over the scene (include/rt_amd.h `rt_bvh_info`).
+#[repr(C)]
+#[derive(Clone, Copy, Default)]
+pub struct rt_bvh_info {
+    pub n_nodes: u64, pub n_triangles: u64, pub n_meshes: u64, pub n_vertices: u64,
+    pub node_bytes: u32, pub tri_bytes: u32, pub max_depth: u32, pub max_leaf: u32,
+    pub build_ms: f64, pub sah_cost: f64, pub n_builds: u32, pub n_refits: u32,
+    pub n_wide_nodes: u64, pub wide_max_depth: u32, pub wide_stack_need: u32,
+}
+/// Opaque host-only tree (no GPU touched): `rt_host_bvh_*`.
+#[repr(C)]
+pub struct rt_host_bvh { _private: [u8; 0] }
+
 extern "C" {
+    pub fn rt_get_counters(ctx: *mut rt_ctx, out: *mut rt_counters) -> c_int;
+    pub fn rt_get_bvh_info(ctx: *mut rt_ctx, out: *mut rt_bvh_info) -> c_int;
+    pub fn rt_read_bvh(ctx: *mut rt_ctx, nodes: *mut c_void, node_bytes_total: usize, tris: *mut c_void, tri_bytes_total: usize) -> c_int;
+    pub fn rt_read_bvh_wide(ctx: *mut rt_ctx, wide_nodes: *mut c_void, bytes_total: usize) -> c_int;
+    pub fn rt_host_bvh_build(triangles: *const rt_triangle, n_triangles: usize, meshes: *const rt_mesh_info, n_meshes: usize,
+        vertices: *const rt_vertex, n_vertices: usize, n_threads: c_int, out: *mut *mut rt_host_bvh, info: *mut rt_bvh_info) -> c_int;
+    pub fn rt_host_bvh_refit(bvh: *mut rt_host_bvh, triangles: *const rt_triangle, n_triangles: usize,
+        vertices: *const rt_vertex, n_vertices: usize, n_threads: c_int) -> c_int;
+    pub fn rt_host_bvh_copy(bvh: *const rt_host_bvh, nodes: *mut c_void, node_bytes_total: usize, tris: *mut c_void, tri_bytes_total: usize) -> c_int;
+    pub fn rt_host_bvh_wide(bvh: *const rt_host_bvh, wide_nodes: *mut c_void, wide_src: *mut c_void, capacity_nodes: usize,
+        n_wide: *mut usize, stack_need: *mut u32) -> c_int;
+    pub fn rt_host_bvh_free(bvh: *mut rt_host_bvh);
     pub fn rt_create(device_ordinal: c_int, out: *mut *mut rt_ctx) -> c_int;
     pub fn rt_destroy(ctx: *mut rt_ctx) -> c_int;
     pub fn rt_set_stream(ctx: *mut rt_ctx, hip_stream: *mut c_void) -> c_int;

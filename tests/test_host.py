@@ -441,3 +441,15 @@ def test_bvh_is_the_same_tree_whatever_the_thread_count():
         if ref is None:
             ref = cur
         assert cur == ref, threads
+
+
+def test_rust_sys_source_binds_every_entry_point_of_the_header():
+    """integration/rt-amd-sys/src/lib.rs is unbuilt source (no Rust toolchain in the image): at least its list of `pub fn`
+    must be the header's list of entry points, so the binding a maintainer would compile cannot silently fall behind."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    header = open(os.path.join(root, "include", "rt_amd.h")).read()
+    rust = open(os.path.join(root, "integration", "rt-amd-sys", "src", "lib.rs")).read()
+    declared = set(re.findall(r"\b(rt_[a-z0-9_]+)\s*\(", header))
+    bound = set(re.findall(r"pub fn (rt_[a-z0-9_]+)", rust))
+    assert declared == bound, (sorted(declared - bound), sorted(bound - declared))
+    assert declared == set(rt.RT_SYMBOLS)

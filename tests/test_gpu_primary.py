@@ -111,3 +111,23 @@ def test_two_contexts_on_one_gpu_render_concurrently():
         for ctx, (rgba_o, prim_o, t_o, _) in ((a, ref[0]), (b, ref[1])):
             assert bitwise_equal(ctx.read_prim_ids(), prim_o) and bitwise_equal(ctx.read_radiance(), rgba_o)
         assert not bitwise_equal(a.read_prim_ids(), b.read_prim_ids())
+
+
+@pytest.mark.parametrize("size", [(4096, 1), (1, 2048), (3, 5), (1, 1), (2047, 3)])
+def test_extreme_frame_shapes(size):
+    """Frames far from tile multiples: one row, one column, a handful of pixels -- every kernel variant, shadow rays and a
+    path-traced sample, against the oracle."""
+    W, H = size
+    app = default_app(W, H)
+    scene = app.prepare_meshinfo()
+    osc, view = oracle_scene(scene), oracle_view(app)
+    rgba_o, prim_o, t_o, rays_o = orc.render_primary(osc, view, orc.FLAG_SHADOW)
+    acc_o, segs_o = orc.render_path(osc, view, 5, 4, seed=2)
+    ctx = None
+    for extra in (0, rt.FLAG_STATIC_GRID, rt.FLAG_WAVE_TRAVERSAL, rt.FLAG_BINARY_TREE):
+        ctx, rgba_g, prim_g, t_g = gpu_render(app, scene, rt.FLAG_SHADOW | extra, ctx=ctx) if ctx else gpu_render(app, scene, rt.FLAG_SHADOW | extra)
+        assert bitwise_equal(prim_g, prim_o) and bitwise_equal(t_g, t_o) and bitwise_equal(rgba_g, rgba_o), (size, extra)
+        assert ctx.counters().rays_primary == W * H
+    assert ctx.render(flags=rt.FLAG_PATH_TRACE, spp=5, max_segments=4, seed=2) == rt.RT_OK
+    assert bitwise_equal(ctx.read_accumulation(), acc_o)
+    ctx.close()

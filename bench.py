@@ -345,6 +345,30 @@ def main():
                     del nodes_h, recs_h, wide_h, tree, rgba_w, prim_w, dw
                 except Exception as ex:                                          # never fail the bench line for it
                     cb["tree_walk"] = {"error": str(ex)[:120]}
+        if not args.no_cpu_baseline and spp and world == 1 and not args.extra_flags:
+            # path-tracing workloads: the reference-shaped loop cannot reach these sizes, so the CPU figure is the oracle's
+            # scalar walk of the device's own tree (oracle/rt_oracle.c orc_render_path_tree), the whole frame, which is
+            # also a whole-frame parity check of the running sums
+            try:
+                import oracle_py as orc
+                view = orc.make_view(m, p, W, H)
+                threads = max(1, min(16, os.cpu_count() or 1))
+                tree = orc.Tree(*ctx.read_bvh(), ctx.read_bvh_wide() if info.n_wide_nodes else None)
+                osc = orc.Scene(scene.triangles, scene.meshes, scene.vertices, scene.materials)
+                ctx.render(flags=flags, **shard)                      # one frame of exactly these samples, no accumulation carried over
+                acc_g = ctx.read_accumulation()
+                t0 = time.perf_counter()
+                acc_w, segs_w, _ = orc.render_path_tree(osc, tree, view, spp=spp, max_segments=segs, seed=1, stream=rank, threads=threads)
+                dt_w = time.perf_counter() - t0
+                out["cpu_baseline"] = {"value": round(segs_w / dt_w / 1e6, 3), "unit": "Mrays/s", "cores": threads, "kind": "port",
+                                       "sample": f"full frame, {segs_w} ray segments, oracle walk of the device's own tree (orc_render_path_tree), {dt_w:.1f} s"}
+                dd = acc_g.astype(np.float64) - acc_w.astype(np.float64)
+                out["parity"] = {"accumulation_identical": bool((acc_g.view(np.uint32) == acc_w.view(np.uint32)).all()),
+                                 "radiance_rmse": float(np.sqrt(np.mean(dd * dd))) / spp, "pixels": int(W * H),
+                                 "segments_equal": bool(segs_w == rays_step)}
+                del tree, acc_w, acc_g, dd
+            except Exception as ex:                                              # never fail the bench line for it
+                out["cpu_baseline"] = {"error": str(ex)[:120]}
         # second denominator: what a plain device-to-device copy reaches on THIS box, read + write bytes
         try:
             src = torch.empty(1 << 28, dtype=torch.float32, device="cuda")       # 1 GiB: beyond the 256 MiB Infinity Cache

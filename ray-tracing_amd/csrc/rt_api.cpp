@@ -226,7 +226,6 @@ int rt_create(int device_ordinal, rt_ctx **out) {
         c->tune.blocks_per_cu = env("RT_TUNE_BLOCKS_PER_CU", 0, 0, 8);
         c->tune.refill_min = env("RT_TUNE_REFILL_MIN", 64, 1, 64);
         c->tune.finish_min = env("RT_TUNE_FINISH_MIN", 64, 1, 64);
-        c->tune.stream_waves = (uint32_t)env("RT_TUNE_STREAM_WAVES", 0, 0, 8);
         c->tune_refit_list_max = (uint32_t)env("RT_TUNE_REFIT_LIST_MAX", 16384, 0, 1 << 24);
         c->tune.vote_node = env("RT_TUNE_VOTE_NODE", 3, 1, 64);
         c->tune.vote_tri = env("RT_TUNE_VOTE_TRI", 1, 1, 64);

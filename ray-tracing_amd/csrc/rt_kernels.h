@@ -23,7 +23,6 @@ struct RtTune {
     uint32_t vote_node, vote_tri;   // relative issue cost of a node step / a triangle step (phase vote)
     uint32_t uni_min;          // lanes that must share one node for the scalar node fetch (65 = never)
     uint32_t wide_vote_node, wide_vote_tri;   // the same vote weights when the 4-wide tree is walked
-    uint32_t stream_waves;     // 0 = by tree size, 6 / 8 = waves per SIMD the persistent kernel is built for
 };
 hipError_t rtk_launch_primary(hipStream_t st, const RtSceneDev &S, const RtViewDev &V, const RtShardDev &sh,
                               uint32_t flags, float *rgba, uint32_t *prim, float *t,

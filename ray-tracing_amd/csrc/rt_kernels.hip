@@ -860,19 +860,14 @@ __device__ __forceinline__ void stream_body(
     }
 }
 
-// The persistent kernel at two register budgets: 8 waves per SIMD (<= 64 VGPRs) for trees that miss the caches -- they need
-// every wave the SIMDs can hold to hide the misses -- and 6 waves per SIMD (<= 80 VGPRs) for trees the caches hold, where
-// fewer register spills are worth more than the two waves (same-box A/B: default scene -5 %, 1 M-triangle soup -1.5 %, the
-// 7.2 M-triangle bench scene +2.6 %: rtk_launch_primary picks by tree size).
+// The persistent kernel is built for 7 waves per SIMD (<= 72 VGPRs): same-box A/B against 8 waves / 64 VGPRs (more spills)
+// and 6 waves / 80 VGPRs: default scene 0.233 / 0.255 / 0.240 ms, 1 M-triangle soup 0.596 / 0.606 / 0.591, 7.2 M-triangle bench
+// scene 0.809 / 0.813 / 0.836.  (The path kernels lose with fewer than 8 waves and keep RT_MIN_WAVES.)
+#ifndef RT_STREAM_WAVES
+#define RT_STREAM_WAVES 7
+#endif
 template <bool COUNT, bool WIDE>
-__global__ __launch_bounds__(RT_BLOCK, RT_MIN_WAVES) void k_stream(
-    RtSceneDev S_, RtViewDev V_, RtShardDev sh_, uint32_t flags, uint32_t refill_min, uint32_t finish_min,
-    uint32_t vote_node, uint32_t vote_tri, uint32_t uni_min, float4 *__restrict__ rgba, uint32_t *__restrict__ prim,
-    float *__restrict__ tout, unsigned long long *__restrict__ counters) {
-    stream_body<COUNT, WIDE>(S_, V_, sh_, flags, refill_min, finish_min, vote_node, vote_tri, uni_min, rgba, prim, tout, counters);
-}
-template <bool COUNT, bool WIDE>
-__global__ __launch_bounds__(RT_BLOCK, 6) void k_stream_w6(
+__global__ __launch_bounds__(RT_BLOCK, RT_STREAM_WAVES) void k_stream(
     RtSceneDev S_, RtViewDev V_, RtShardDev sh_, uint32_t flags, uint32_t refill_min, uint32_t finish_min,
     uint32_t vote_node, uint32_t vote_tri, uint32_t uni_min, float4 *__restrict__ rgba, uint32_t *__restrict__ prim,
     float *__restrict__ tout, unsigned long long *__restrict__ counters) {
@@ -1361,17 +1356,14 @@ hipError_t rtk_launch_primary(hipStream_t st, const RtSceneDev &S, const RtViewD
         uint32_t per_cu = tune.blocks_per_cu;
         const bool w_ = S.n_wide != 0u && !(flags & RT_FLAG_BINARY_TREE);
         const size_t tree = (size_t)(w_ ? S.n_wide : S.n_nodes) * sizeof(RtBvhNode) + (size_t)S.n_recs * sizeof(RtTriRecord);
-        // 6 waves per SIMD with the larger register budget for trees up to 128 MiB (RT_TUNE_STREAM_WAVES = 6 / 8 forces one)
-        const bool six = tune.stream_waves ? tune.stream_waves == 6u : tree <= ((size_t)128 << 20);
         if (per_cu == 0) per_cu = tree <= ((size_t)4 << 20) ? 3u : (tree <= ((size_t)16 << 20) ? 5u : 8u);
-        if (six && per_cu > 6u) per_cu = 6u;
+        if (per_cu > RT_STREAM_WAVES) per_cu = RT_STREAM_WAVES;      // what a CU can hold: later blocks would only find empty queues
         uint32_t need = (sh.n_owned * sh.tile * sh.tile + RT_BLOCK - 1) / RT_BLOCK;
         uint32_t grid = tune.cus * per_cu < need ? tune.cus * per_cu : need;
         if (grid == 0) return hipSuccess;
         const bool wide = S.n_wide != 0u && !(flags & RT_FLAG_BINARY_TREE);
 #define RT_LAUNCH_STREAM(C, W, VN, VT) \
-    do { if (six) hipLaunchKernelGGL((k_stream_w6<C, W>), dim3(grid), dim3(RT_BLOCK), 0, st, S, V, sh, flags, tune.refill_min, tune.finish_min, VN, VT, tune.uni_min, (float4 *)rgba, prim, t, counters); \
-      else hipLaunchKernelGGL((k_stream<C, W>), dim3(grid), dim3(RT_BLOCK), 0, st, S, V, sh, flags, tune.refill_min, tune.finish_min, VN, VT, tune.uni_min, (float4 *)rgba, prim, t, counters); } while (0)
+    hipLaunchKernelGGL((k_stream<C, W>), dim3(grid), dim3(RT_BLOCK), 0, st, S, V, sh, flags, tune.refill_min, tune.finish_min, VN, VT, tune.uni_min, (float4 *)rgba, prim, t, counters)
         if (wide) { if (count) RT_LAUNCH_STREAM(true, true, tune.wide_vote_node, tune.wide_vote_tri); else RT_LAUNCH_STREAM(false, true, tune.wide_vote_node, tune.wide_vote_tri); }
         else { if (count) RT_LAUNCH_STREAM(true, false, tune.vote_node, tune.vote_tri); else RT_LAUNCH_STREAM(false, false, tune.vote_node, tune.vote_tri); }
 #undef RT_LAUNCH_STREAM

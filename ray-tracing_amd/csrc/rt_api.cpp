@@ -222,7 +222,7 @@ int rt_create(int device_ordinal, rt_ctx **out) {
             return (v < (long)lo || v > (long)hi) ? dflt : (uint32_t)v;
         };
         c->tune.cus = (uint32_t)prop.multiProcessorCount;
-        c->tune.persist_blocks = c->tune.cus * 8;
+        c->tune.persist_blocks = c->tune.cus * (uint32_t)env("RT_TUNE_PERSIST_PER_CU", 7, 1, 8);   // what a CU holds of the 7-wave kernels
         c->tune.blocks_per_cu = env("RT_TUNE_BLOCKS_PER_CU", 0, 0, 8);
         c->tune.refill_min = env("RT_TUNE_REFILL_MIN", 64, 1, 64);
         c->tune.finish_min = env("RT_TUNE_FINISH_MIN", 64, 1, 64);

@@ -15,7 +15,7 @@ uint32_t rtk_primary_blocks(const RtShardDev &sh);
 // Live path of ray_tracing.wgsl:173-211 (+ build-defined shadow ray): ray gen, closest hit,
 // shade, outputs.  flags: RT_FLAG_* of rt_amd.h (SHADOW, NO_MESH_CULL, BRUTE_FORCE, COUNTERS).
 struct RtTune {
-    uint32_t persist_blocks;   // grid of the persistent kernels (CUs x 8 resident blocks per CU)
+    uint32_t persist_blocks;   // grid of the persistent path kernels (CUs x resident blocks per CU)
     uint32_t cus;              // compute units of the device
     uint32_t blocks_per_cu;    // k_stream: resident blocks per CU; 0 = by BVH size (rtk_launch_primary)
     uint32_t refill_min;       // idle lanes in a wave that trigger a refill (64 = whole 8x8 blocks only)

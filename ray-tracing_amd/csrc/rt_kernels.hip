@@ -12,12 +12,14 @@
 
 // Per-lane traversal stack: the first RT_STACK_LDS entries live in LDS (stack[level][thread], bank
 // = lane: conflict-free), deeper levels spill to a private array.  16 entries x 256 threads = 16 KiB
-// per block and <= 64 VGPRs admit 8 waves/SIMD; measured +10 % over 24 entries / 6 waves.
+// per block.  Every traversal kernel is built for 7 waves per SIMD (<= 72 VGPRs): 8 waves / 64 VGPRs spill more, 6 waves hide
+// less latency (same-box A/Bs with grids sized to match: k_stream below; path kernels 7 vs 8 waves: 4K frame -0.9 %, 10 M
+// triangles -2.1 %, 4 spp at 1080p -2.3 %; 6 waves +4 % / +3 % / +1.5 %).
 #ifndef RT_STACK_LDS
 #define RT_STACK_LDS 16
 #endif
 #ifndef RT_MIN_WAVES
-#define RT_MIN_WAVES 8
+#define RT_MIN_WAVES 7
 #endif
 // private part: a binary tree needs <= RT_MAX_DEPTH entries in all, a 4-wide tree up to 3 per level (the host
 // checks RtWideTree::stack_need against RT_STACK_CAP before it enables the wide tree)
@@ -862,9 +864,9 @@ __device__ __forceinline__ void stream_body(
 
 // The persistent kernel is built for 7 waves per SIMD (<= 72 VGPRs): same-box A/B against 8 waves / 64 VGPRs (more spills)
 // and 6 waves / 80 VGPRs: default scene 0.233 / 0.255 / 0.240 ms, 1 M-triangle soup 0.596 / 0.606 / 0.591, 7.2 M-triangle bench
-// scene 0.809 / 0.813 / 0.836.  (The path kernels lose with fewer than 8 waves and keep RT_MIN_WAVES.)
+// scene 0.809 / 0.813 / 0.836.  (The path kernels: RT_MIN_WAVES above.)
 #ifndef RT_STREAM_WAVES
-#define RT_STREAM_WAVES 7
+#define RT_STREAM_WAVES RT_MIN_WAVES
 #endif
 template <bool COUNT, bool WIDE>
 __global__ __launch_bounds__(RT_BLOCK, RT_STREAM_WAVES) void k_stream(

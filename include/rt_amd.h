@@ -56,7 +56,9 @@ typedef struct rt_ctx rt_ctx;
 int rt_create(int device_ordinal, rt_ctx **out);
 int rt_destroy(rt_ctx *ctx);
 /* Run all work of this context on an existing HIP stream (hipStream_t passed as void*);
- * NULL restores the context's own stream. */
+ * NULL restores the context's own stream (created hipStreamNonBlocking: it does NOT order against
+ * HIP's null stream); RT_STREAM_NULL selects HIP's null stream itself, explicitly. */
+#define RT_STREAM_NULL ((void *)(intptr_t)-1)
 int rt_set_stream(rt_ctx *ctx, void *hip_stream);
 
 /* ---- scene upload: replaces as_bind_group's per-frame buffer creation ---------------
@@ -133,7 +135,8 @@ typedef struct {
     uint32_t stream_id;      /* RNG stream (= rank for sample slicing) */
     uint32_t shard_rank;     /* screen-tile sharding: this context renders the tiles whose */
     uint32_t shard_count;    /*   index % shard_count == shard_rank; 0 or 1 = all tiles  */
-    uint32_t tile_size;      /* shard tile edge in pixels (0 = 64) */
+    uint32_t tile_size;      /* tile edge in pixels, a multiple of 16; 0 = 64 when shard_count > 1 (the tiles ranks own),
+                                32 otherwise (then a tile is only the unit dealt to the kernel's work queues) */
     uint32_t _reserved;
 } rt_render_params;
 
@@ -153,6 +156,11 @@ int rt_read_prim_ids(rt_ctx *ctx, uint32_t *prim, size_t n);
 int rt_read_hit_t(rt_ctx *ctx, float *t, size_t n);
 int rt_read_bgra8_srgb(rt_ctx *ctx, uint8_t *bgra, size_t n_bytes);
 int rt_read_accumulation(rt_ctx *ctx, float *accum, size_t n_floats);
+/* The same Bgra8UnormSrgb encode (src/pipeline.rs:56-60) for ANY linear RGBA f32 frame the caller holds on the host
+ * (e.g. one combined from several GPUs): n_pixels * 4 floats in, n_pixels * 4 bytes out, through the device kernel.
+ * Byte work, exact: a colour byte is the correctly rounded round(255 * srgb_oetf(x)) (threshold table generated by
+ * tools/gen_srgb_table.py), alpha is floor(255 * clamp(a) + 0.5); NaN encodes as 0. */
+int rt_encode_bgra8_srgb(rt_ctx *ctx, const float *rgba, size_t n_pixels, uint8_t *bgra);
 
 /* Device-side access for callers that keep results on the GPU (multi-GPU combine with RCCL):
  * pointers into the context's own buffers, valid until the next rt_set_view with a different
@@ -160,6 +168,19 @@ int rt_read_accumulation(rt_ctx *ctx, float *accum, size_t n_floats);
 int rt_device_buffers(rt_ctx *ctx, void **d_radiance, void **d_prim, void **d_accum);
 /* radiance = accum / total_samples on the device (after an external reduce). */
 int rt_resolve_accumulation(rt_ctx *ctx, uint32_t total_samples);
+
+/* ---- multi-GPU tile exchange (the reference is single-GPU, src/node.rs:77 is its one launch) --------
+ * With shard_count ranks, rank r owns the tile_size x tile_size screen tiles g = r, r + shard_count, ... (g counted
+ * row-major over the covered rect), exactly the tiles rt_render(shard_rank = r) writes.  rt_pack_tiles copies the
+ * radiance of this context's own tiles into ONE contiguous device buffer (tile after tile in owned order, tile_size^2
+ * float4 each, zeros where an edge tile leaves the covered rect) -- the message a rank sends to the gathering rank;
+ * rt_unpack_tiles scatters the packed tiles of n_ranks ranks, slot_bytes apart in d_packed (slot s = rank
+ * first_rank + s), into this context's radiance buffer.  rt_tile_slot_bytes = the packed size of the rank that owns
+ * the most tiles (rank 0): a slot size that fits every rank.  Device pointers; asynchronous on the context's stream. */
+int rt_tile_slot_bytes(rt_ctx *ctx, uint32_t shard_count, uint32_t tile_size, size_t *bytes);
+int rt_pack_tiles(rt_ctx *ctx, uint32_t shard_rank, uint32_t shard_count, uint32_t tile_size, void *d_packed, size_t bytes);
+int rt_unpack_tiles(rt_ctx *ctx, uint32_t first_rank, uint32_t n_ranks, uint32_t shard_count, uint32_t tile_size,
+                    const void *d_packed, size_t slot_bytes);
 
 /* ---- counters, introspection, errors ------------------------------------------------- */
 typedef struct {

@@ -113,6 +113,13 @@ extern "C" {
     pub fn rt_device_buffers(ctx: *mut rt_ctx, d_radiance: *mut *mut c_void, d_prim: *mut *mut c_void,
         d_accum: *mut *mut c_void) -> c_int;
     pub fn rt_resolve_accumulation(ctx: *mut rt_ctx, total_samples: u32) -> c_int;
+    /// Bgra8UnormSrgb encode of any host RGBA f32 frame through the device kernel (exact bytes).
+    pub fn rt_encode_bgra8_srgb(ctx: *mut rt_ctx, rgba: *const f32, n_pixels: usize, bgra: *mut u8) -> c_int;
+    /// Multi-GPU tile exchange: packed size of the largest rank's tiles, pack own tiles, scatter peers' tiles.
+    pub fn rt_tile_slot_bytes(ctx: *mut rt_ctx, shard_count: u32, tile_size: u32, bytes: *mut usize) -> c_int;
+    pub fn rt_pack_tiles(ctx: *mut rt_ctx, shard_rank: u32, shard_count: u32, tile_size: u32, d_packed: *mut c_void, bytes: usize) -> c_int;
+    pub fn rt_unpack_tiles(ctx: *mut rt_ctx, first_rank: u32, n_ranks: u32, shard_count: u32, tile_size: u32,
+        d_packed: *const c_void, slot_bytes: usize) -> c_int;
     pub fn rt_last_error(ctx: *mut rt_ctx) -> *const c_char;
     pub fn rt_status_string(status: c_int) -> *const c_char;
     pub fn rt_version() -> *const c_char;

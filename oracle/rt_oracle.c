@@ -234,7 +234,10 @@ static inline __attribute__((always_inline)) void tw_walk(const orc_scene *s, co
     float t = INFINITY; uint32_t seq = 0xFFFFFFFFu, rec = 0xFFFFFFFFu;
     uint64_t n_nodes = 0, n_tris = 0, n_culls = 0;
     memset(out, 0, sizeof *out); out->prim = ORC_MISS_PRIM;
-    if ((wide ? tr->n_wide : tr->n_nodes) != 0) {
+    /* a ray with a NaN in it misses everything in the reference's loop (every compare of wgsl:137 is false): the walk
+     * ends it before it starts, as the kernels do (the wide step's min/max would drop the NaN and visit every node) */
+    const int nan_ray = o.x != o.x || o.y != o.y || o.z != o.z || d.x != d.x || d.y != d.y || d.z != d.z;
+    if ((wide ? tr->n_wide : tr->n_nodes) != 0 && !nan_ray) {
         v3 inv = V(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
         if (wide) inv = V(fminf(fmaxf(inv.x, -TW_INV_MAX), TW_INV_MAX), fminf(fmaxf(inv.y, -TW_INV_MAX), TW_INV_MAX),
                           fminf(fmaxf(inv.z, -TW_INV_MAX), TW_INV_MAX));
@@ -592,17 +595,26 @@ static uint8_t unorm8(float x) {
     if (x > 1.0f) x = 1.0f;
     return (uint8_t)floorf(x * 255.0f + 0.5f);
 }
-static float srgb_oetf(float x) {
-    if (!(x > 0.0f)) return 0.0f;
-    if (x >= 1.0f) return 1.0f;
-    if (x <= 0.0031308f) return x * 12.92f;
-    return 1.055f * (float)pow((double)x, 1.0 / 2.4) - 0.055f;
+/* Colour channels: byte = round(255 * srgb_oetf(x)), as the number of linear-space thresholds <= x.  srgb_table.h
+ * (tools/gen_srgb_table.py) holds, for k = 1..255, the smallest binary32 x whose byte is >= k, exactly rounded from
+ * the OETF -- float compares only, so this function has one answer on every machine (a pow() here and a powf() on
+ * the device differed by 1 LSB on ~1 % of bytes).  NaN and x <= 0 give 0, x >= 1 gives 255.
+ * tests/test_srgb_table.py pins the table to the formula evaluated in binary64. */
+#include "srgb_table.h"
+static uint8_t srgb_byte(float x) {
+    uint32_t n = 0;
+    for (uint32_t step = 128; step; step >>= 1) {
+        union { uint32_t u; float f; } t;
+        t.u = RT_SRGB_THRESHOLD_BITS[n + step - 1];
+        if (t.f <= x) n += step;
+    }
+    return (uint8_t)n;
 }
 void orc_encode_bgra8_srgb(const float *rgba, size_t n_px, uint8_t *bgra) {
     for (size_t i = 0; i < n_px; ++i) {
-        bgra[4 * i + 0] = unorm8(srgb_oetf(rgba[4 * i + 2]));
-        bgra[4 * i + 1] = unorm8(srgb_oetf(rgba[4 * i + 1]));
-        bgra[4 * i + 2] = unorm8(srgb_oetf(rgba[4 * i + 0]));
+        bgra[4 * i + 0] = srgb_byte(rgba[4 * i + 2]);
+        bgra[4 * i + 1] = srgb_byte(rgba[4 * i + 1]);
+        bgra[4 * i + 2] = srgb_byte(rgba[4 * i + 0]);
         bgra[4 * i + 3] = unorm8(rgba[4 * i + 3]); /* alpha is linear */
     }
 }

@@ -80,6 +80,7 @@ class EntityView(C.Structure):
 RT_SYMBOLS = ["rt_create", "rt_destroy", "rt_set_stream", "rt_upload_scene", "rt_upload_scene_ex", "rt_update_vertices", "rt_update_vertex_range", "rt_host_bvh_refit", "rt_set_view", "rt_render",
               "rt_synchronize", "rt_read_radiance", "rt_read_prim_ids", "rt_read_hit_t", "rt_read_bgra8_srgb",
               "rt_read_accumulation", "rt_device_buffers", "rt_resolve_accumulation", "rt_get_counters",
+              "rt_encode_bgra8_srgb", "rt_tile_slot_bytes", "rt_pack_tiles", "rt_unpack_tiles",
               "rt_get_bvh_info", "rt_read_bvh", "rt_read_bvh_wide", "rt_host_bvh_build", "rt_host_bvh_copy", "rt_host_bvh_wide", "rt_host_bvh_free", "rt_last_error", "rt_status_string", "rt_version"]
 RTH_SYMBOLS = ["rth_app_create", "rth_app_destroy", "rth_app_finish", "rth_app_update", "rth_app_ctx",
                "rth_last_error", "rth_add_mesh", "rth_add_cuboid", "rth_add_plane", "rth_add_icosphere",
@@ -117,6 +118,11 @@ def lib():
         "rt_read_accumulation": (i, [vp, vp, sz]),
         "rt_device_buffers": (i, [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]),
         "rt_resolve_accumulation": (i, [vp, u32]),
+        "rt_encode_bgra8_srgb": (i, [vp, vp, sz, vp]),
+        "rt_tile_slot_bytes": (i, [vp, u32, u32, C.POINTER(sz)]),
+        "rt_pack_tiles": (i, [vp, u32, u32, u32, vp, sz]),
+        "rt_unpack_tiles": (i, [vp, u32, u32, u32, u32, vp, sz]),
+        "rt_render_static": (i, [vp, C.POINTER(RenderParams), vp, vp, vp, vp, sz]),
         "rt_get_counters": (i, [vp, C.POINTER(Counters)]), "rt_get_bvh_info": (i, [vp, C.POINTER(BvhInfo)]),
         "rt_read_bvh": (i, [vp, vp, sz, vp, sz]),
         "rt_host_bvh_build": (i, [vp, sz, vp, sz, vp, sz, i, C.POINTER(vp), C.POINTER(BvhInfo)]),
@@ -339,8 +345,36 @@ class Context:
                          shard_rank, shard_count, tile_size, 0)
         return self._chk(lib().rt_render(self._h, C.byref(p)), allow_not_ready=True)
 
+    def render_static(self, d_radiance, d_prim, d_hit_t, d_accum, n_pixels, flags=0, spp=0, sample_first=0, max_segments=0,
+                      seed=0, stream_id=0, shard_rank=0, shard_count=0, tile_size=0, frame_count=0):
+        """rt_render_static: the same frame into the CALLER's device buffers (raw device pointers), allocating nothing."""
+        p = RenderParams(C.sizeof(RenderParams), flags, frame_count, spp, sample_first, max_segments, seed, stream_id,
+                         shard_rank, shard_count, tile_size, 0)
+        return self._chk(lib().rt_render_static(self._h, C.byref(p), C.c_void_p(d_radiance), C.c_void_p(d_prim),
+                                                C.c_void_p(d_hit_t), C.c_void_p(d_accum), n_pixels), allow_not_ready=True)
+
     def synchronize(self):
         self._chk(lib().rt_synchronize(self._h))
+
+    def encode_bgra8_srgb(self, rgba):
+        """Any (..., 4) float32 host array through the device's Bgra8UnormSrgb encode (k_encode_bgra8)."""
+        rgba = np.ascontiguousarray(rgba, dtype=np.float32)
+        out = np.empty(rgba.shape, dtype=np.uint8)
+        self._chk(lib().rt_encode_bgra8_srgb(self._h, rgba.ctypes.data, rgba.size // 4, out.ctypes.data))
+        return out
+
+    def tile_slot_bytes(self, shard_count, tile_size=64):
+        n = C.c_size_t()
+        self._chk(lib().rt_tile_slot_bytes(self._h, shard_count, tile_size, C.byref(n)))
+        return n.value
+
+    def pack_tiles(self, shard_rank, shard_count, tile_size, d_packed, n_bytes):
+        """This rank's shard tiles of the radiance buffer, packed, into the device buffer d_packed (raw pointer)."""
+        self._chk(lib().rt_pack_tiles(self._h, shard_rank, shard_count, tile_size, C.c_void_p(d_packed), n_bytes))
+
+    def unpack_tiles(self, first_rank, n_ranks, shard_count, tile_size, d_packed, slot_bytes):
+        """Packed tiles of ranks [first_rank, first_rank + n_ranks), slot_bytes apart in d_packed, into the radiance buffer."""
+        self._chk(lib().rt_unpack_tiles(self._h, first_rank, n_ranks, shard_count, tile_size, C.c_void_p(d_packed), slot_bytes))
 
     def _read(self, fn, dtype, shape):
         out = np.empty(shape, dtype=dtype)

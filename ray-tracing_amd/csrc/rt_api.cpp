@@ -60,7 +60,10 @@ struct rt_ctx {
     float *d_rgba = nullptr, *d_accum = nullptr, *d_t = nullptr;
     uint32_t *d_prim = nullptr;
     uint8_t *d_bgra = nullptr;
-    uint64_t coverage_sig = 0;       // what the buffers were last cleared for
+    // what the buffers were last cleared for: (rank, count, tile, vx, vy, vw, vh, partial), compared field by field
+    uint32_t coverage[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    bool coverage_valid = false;
+    hipEvent_t ev_update[2] = {nullptr, nullptr};   // timing of rt_update_vertices / rt_update_vertex_range (created once)
     uint32_t accum_samples = 0;
     bool accum_dirty = false;        // camera moved: the next path-traced frame restarts accumulation
 
@@ -77,6 +80,8 @@ struct rt_ctx {
     uint64_t primary_total = 0;
 
     RtTune tune{};
+    void *static_scratch = nullptr;       // device address of rt_kernels.hip's static scratch array on THIS device (rt_render_static)
+    uint32_t static_accum_samples = 0;    // samples in the caller's accumulation buffer (rt_render_static)
     uint32_t tune_wide = 0;               // build and walk the 4-wide quantised tree
     uint32_t tune_sample_batch = 16;      // path tracing: most samples of a pixel traced per launch (16, 4 or 1 are used)
     RtWideTree wide_host;
@@ -243,6 +248,9 @@ int rt_create(int device_ordinal, rt_ctx **out) {
         if ((e = hipMalloc((void **)&c->d_cnt, RT_CNT_N * sizeof(unsigned long long))) != hipSuccess) { rc = fail(nullptr, RT_ERR_HIP, "hipMalloc counters", e); break; }
         if ((e = hipHostMalloc((void **)&c->h_cnt, RT_CNT_N * sizeof(unsigned long long), hipHostMallocDefault)) != hipSuccess) { rc = fail(nullptr, RT_ERR_HIP, "hipHostMalloc counters", e); break; }
         std::memset(c->h_cnt, 0, RT_CNT_N * sizeof(unsigned long long));
+        // the static scratch array of rt_render_static: every device holds its own copy at its own address, so the
+        // address is asked for here, once per context, with this context's device current
+        if ((e = rtk_static_scratch_address(&c->static_scratch)) != hipSuccess) { rc = fail(nullptr, RT_ERR_HIP, "hipGetSymbolAddress(rt_static_scratch)", e); break; }
     } while (0);
     if (rc != RT_OK) { rt_destroy(c); return rc; }
     *out = c;
@@ -252,12 +260,13 @@ int rt_create(int device_ordinal, rt_ctx **out) {
 int rt_destroy(rt_ctx *c) {
     if (!c) return RT_OK;
     (void)hipSetDevice(c->device);
-    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    (void)hipStreamSynchronize(c->stream);
     free_scene(c);
     free_frame(c);
     if (c->d_cnt) (void)hipFree(c->d_cnt);
     if (c->h_cnt) (void)hipHostFree(c->h_cnt);
     for (hipEvent_t ev : c->ev) (void)hipEventDestroy(ev);
+    for (hipEvent_t ev : c->ev_update) if (ev) (void)hipEventDestroy(ev);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
     return RT_OK;
@@ -266,8 +275,9 @@ int rt_destroy(rt_ctx *c) {
 int rt_set_stream(rt_ctx *c, void *hip_stream) {
     if (!c) return RT_ERR_ARG;
     (void)hipSetDevice(c->device);
-    if (c->stream) HIPCHK(c, hipStreamSynchronize(c->stream));
-    c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (hip_stream == RT_STREAM_NULL) c->stream = nullptr;          // HIP's null stream, asked for explicitly
+    else c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
     return RT_OK;
 }
 
@@ -524,7 +534,7 @@ int rt_upload_scene_ex(rt_ctx *c, const rt_triangle *tris, size_t n_tris, const 
     c->bvh_host_stale = false;
     c->has_scene = true;
     c->accum_samples = 0;
-    c->coverage_sig = 0;
+    c->coverage_valid = false;
     return RT_OK;
 }
 
@@ -568,8 +578,8 @@ int rt_update_vertices(rt_ctx *c, const rt_vertex *verts, size_t n_verts, const 
                 for (const rt_triangle &T : c->h_tris) if (T.indices[0] == i || T.indices[1] == i || T.indices[2] == i) { used = true; break; }
                 if (used) return fail(c, RT_ERR_SCENE, "rt_update_vertices: non-finite vertex, rebuild with rt_upload_scene");
             }
-        hipEvent_t e0 = nullptr, e1 = nullptr;
-        HIPCHK(c, hipEventCreate(&e0)); HIPCHK(c, hipEventCreate(&e1));
+        for (hipEvent_t &ev : c->ev_update) if (!ev) HIPCHK(c, hipEventCreate(&ev));
+        const hipEvent_t e0 = c->ev_update[0], e1 = c->ev_update[1];
         if (n_verts) HIPCHK(c, hipMemcpyAsync(c->d_verts, verts, n_verts * sizeof(rt_vertex), hipMemcpyHostToDevice, c->stream));
         if (n_meshes) HIPCHK(c, hipMemcpyAsync(c->d_meshes, meshes, n_meshes * sizeof(rt_mesh_info), hipMemcpyHostToDevice, c->stream));
         HIPCHK(c, hipEventRecord(e0, c->stream));
@@ -586,7 +596,6 @@ int rt_update_vertices(rt_ctx *c, const rt_vertex *verts, size_t n_verts, const 
         HIPCHK(c, hipStreamSynchronize(c->stream));   // host arrays are borrowed for this call only
         float ms = 0.0f;
         HIPCHK(c, hipEventElapsedTime(&ms, e0, e1));
-        (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
         refit_ms = ms;
         c->bvh_host_stale = true;
     }
@@ -683,8 +692,8 @@ int rt_update_vertex_range(rt_ctx *c, const rt_vertex *verts, size_t first_verte
         }
     }
     if (!by_list && !c->d_dirty && nn) HIPCHK(c, hipMalloc(&c->d_dirty, nn));
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    HIPCHK(c, hipEventCreate(&e0)); HIPCHK(c, hipEventCreate(&e1));
+    for (hipEvent_t &ev : c->ev_update) if (!ev) HIPCHK(c, hipEventCreate(&ev));
+    const hipEvent_t e0 = c->ev_update[0], e1 = c->ev_update[1];
     if (n_verts) HIPCHK(c, hipMemcpyAsync((rt_vertex *)c->d_verts + first_vertex, verts, n_verts * sizeof(rt_vertex), hipMemcpyHostToDevice, c->stream));
     if (n_meshes) HIPCHK(c, hipMemcpyAsync((rt_mesh_info *)c->d_meshes + first_mesh, meshes, n_meshes * sizeof(rt_mesh_info), hipMemcpyHostToDevice, c->stream));
     if (by_list && !list.empty()) HIPCHK(c, hipMemcpyAsync(c->d_list, list.data(), list.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
@@ -710,7 +719,6 @@ int rt_update_vertex_range(rt_ctx *c, const rt_vertex *verts, size_t first_verte
     HIPCHK(c, hipStreamSynchronize(c->stream));   // host arrays are borrowed for this call only
     float ms = 0.0f;
     HIPCHK(c, hipEventElapsedTime(&ms, e0, e1));
-    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     c->bvh_host_stale = true;
     // out of the wide step's coordinate range: binary tree until a full update or upload shows everything is back in
     if (!(amax * 1.0001f < RT_WIDE_COORD_MAX)) c->S.n_wide = 0;
@@ -732,18 +740,26 @@ int rt_set_view(rt_ctx *c, const float m[16], const float pos[3], uint32_t width
         if (vw == 0 || vh == 0 || (uint64_t)vx + vw > width || (uint64_t)vy + vh > height)
             return fail(c, RT_ERR_ARG, "rt_set_view: viewport outside the target");
     }
+    // a NaN or infinite matrix / position makes every ray of the frame NaN: refused here, not traced
+    for (int k = 0; k < 16; ++k) if (!std::isfinite(m[k])) return fail(c, RT_ERR_ARG, "rt_set_view: world_from_clip is not finite");
+    for (int k = 0; k < 3; ++k) if (!std::isfinite(pos[k])) return fail(c, RT_ERR_ARG, "rt_set_view: world_position is not finite");
     HIPCHK(c, hipSetDevice(c->device));
     size_t n_px = (size_t)width * height;
     if (n_px != c->n_px || c->V.width != width) {
         HIPCHK(c, hipStreamSynchronize(c->stream));
+        // until every buffer of the new size exists there is no view: a failed allocation leaves rt_render at
+        // RT_NOT_READY instead of launching on freed or NULL buffers
+        const bool had_view = c->has_view;
+        c->has_view = false;
+        c->coverage_valid = false;
         free_frame(c);
         HIPCHK(c, hipMalloc((void **)&c->d_rgba, n_px * 16));
         HIPCHK(c, hipMalloc((void **)&c->d_accum, n_px * 16));
         HIPCHK(c, hipMalloc((void **)&c->d_t, n_px * 4));
         HIPCHK(c, hipMalloc((void **)&c->d_prim, n_px * 4));
         c->n_px = n_px;
-        c->coverage_sig = 0;
         c->accum_samples = 0;
+        c->has_view = had_view;
     }
     if (c->has_view && (std::memcmp(c->V.m, m, 64) != 0 || std::memcmp(c->V.pos, pos, 12) != 0))
         c->accum_dirty = true;       // accumulation resets on camera movement (intent of src/scene.rs:94-96)
@@ -755,57 +771,145 @@ int rt_set_view(rt_ctx *c, const float m[16], const float pos[3], uint32_t width
     return RT_OK;
 }
 
-static int clear_outputs(rt_ctx *c) {
-    HIPCHK(c, hipMemsetAsync(c->d_rgba, 0, c->n_px * 16, c->stream));
-    HIPCHK(c, hipMemsetAsync(c->d_t, 0, c->n_px * 4, c->stream));
-    HIPCHK(c, hipMemsetAsync(c->d_prim, 0xFF, c->n_px * 4, c->stream));
+// Where one frame's results and scratch live: the context's own buffers (rt_render) or the caller's outputs plus
+// the static scratch array (rt_render_static).
+struct RenderTargets {
+    float *rgba, *accum, *t;
+    uint32_t *prim;
+    unsigned long long *cnt;       // counters + work-queue heads (RT_CNT_N words)
+    RtPathQueue qa, qb;            // path queues, capacity q_cap paths each
+    float *contrib;                // per-sample contribution planes: max_batch planes of n_px float4
+    size_t q_cap;
+    uint32_t max_batch;            // most samples of a pixel traced per launch (16, 4 or 1)
+};
+
+static int clear_outputs(rt_ctx *c, const RenderTargets &T) {
+    HIPCHK(c, hipMemsetAsync(T.rgba, 0, c->n_px * 16, c->stream));
+    HIPCHK(c, hipMemsetAsync(T.t, 0, c->n_px * 4, c->stream));
+    HIPCHK(c, hipMemsetAsync(T.prim, 0xFF, c->n_px * 4, c->stream));
+    return RT_OK;
+}
+
+// rt_render's parameter block, checked and defaulted; the shard description for the kernels
+static int check_params(rt_ctx *c, const rt_render_params *params, rt_render_params &P, RtShardDev &sh, bool &partial) {
+    std::memset(&P, 0, sizeof P);
+    if (params) {
+        if (params->struct_size != sizeof(rt_render_params)) return fail(c, RT_ERR_ARG, "rt_render: struct_size mismatch");
+        P = *params;
+    }
+    if (!c->has_scene || !c->has_view || !c->n_px || !c->d_rgba) return RT_NOT_READY;   // src/node.rs:52-56: skip silently
+    if (P.shard_count == 0) P.shard_count = 1;
+    // default tile: 64 px when tiles are what ranks own (SURVEY 8e), 32 px when they are only k_stream's unit of work
+    // distribution over the XCD queues (tools/tile_sweep.py: 16 / 32 / 64 / 128 / 256 px: 0.82 / 0.79 / 0.80 / 0.81 / 0.89 ms)
+    if (P.tile_size == 0) P.tile_size = P.shard_count > 1 ? 64 : 32;
+    if (P.tile_size % RT_WORK_TILE != 0 || P.tile_size > 4096) return fail(c, RT_ERR_ARG, "rt_render: tile_size must be a multiple of 16");
+    if (P.shard_rank >= P.shard_count) return fail(c, RT_ERR_ARG, "rt_render: shard_rank >= shard_count");
+    sh.rank = P.shard_rank; sh.count = P.shard_count; sh.tile = P.tile_size;
+    sh.tiles_x = (c->V.vw + sh.tile - 1) / sh.tile;
+    sh.tiles_y = (c->V.vh + sh.tile - 1) / sh.tile;
+    uint32_t n_tiles = sh.tiles_x * sh.tiles_y;
+    sh.n_owned = n_tiles > sh.rank ? (n_tiles - sh.rank + sh.count - 1) / sh.count : 0;
+    partial = sh.count > 1 || c->V.vw != c->V.width || c->V.vh != c->V.height;
+    for (int k = 0; k < 3; ++k)      // a camera beyond the wide step's coordinate range: binary tree (rt_layout.h)
+        if (!(std::fabs(c->V.pos[k]) < RT_WIDE_COORD_MAX)) P.flags |= RT_FLAG_BINARY_TREE;
+    if (P.flags & RT_FLAG_PATH_TRACE) {
+        if (P.spp == 0) P.spp = 1;
+        if (P.max_segments == 0) P.max_segments = 4;   // reference shape: 4 segments (wgsl:185)
+        if (c->n_px > ((size_t)1 << 26)) return fail(c, RT_ERR_ARG, "rt_render: path tracing supports at most 2^26 pixels");
+    }
+    return RT_OK;
+}
+
+// samples of a pixel traced per launch: 16 or 4 where there are that many left and the queues hold them (rt_kernels.hip
+// k_path_start), else 1.  Bounded by the queue capacity, RT_TUNE_SAMPLE_BATCH and the magnified grid's 2^31 threads.
+static uint32_t batch_of(const rt_ctx *c, const RenderTargets &T, uint32_t left) {
+    uint32_t k2 = 1;
+    for (uint32_t cand : {4u, 16u})
+        if (cand <= left && cand <= T.max_batch && c->n_px * cand <= T.q_cap &&
+            ((uint64_t)c->V.width << (cand == 4u ? 1 : 2)) * ((uint64_t)c->V.height << (cand == 4u ? 1 : 2)) <= (1ull << 31)) k2 = cand;
+    return k2;
+}
+
+// The launches of one frame.  No allocation, no synchronisation: everything is enqueued on the context's stream.
+static int launch_frame(rt_ctx *c, const rt_render_params &P, const RtShardDev &sh, bool partial, const RenderTargets &T,
+                        uint32_t *accum_samples, uint32_t *launches_out) {
+    HIPCHK(c, hipMemsetAsync(T.cnt, 0, RT_CNT_N * sizeof(unsigned long long), c->stream));
+    uint32_t launches = 0;
+    if (!(P.flags & RT_FLAG_PATH_TRACE)) {
+        HIPCHK(c, rtk_launch_primary(c->stream, c->S, c->V, sh, P.flags, T.rgba, T.prim, T.t, T.cnt, c->tune));
+        launches = 1;
+    } else {
+        uint32_t cap1 = (uint32_t)((size_t)rtk_primary_blocks(sh) * RT_BLOCK);
+        if (cap1 > c->n_px) cap1 = (uint32_t)c->n_px;
+        for (uint32_t s = 0, b = 0; s < P.spp; s += b) {
+            b = batch_of(c, T, P.spp - s);                 // 16, 4 or 1 samples of every pixel in this round of launches
+            const uint32_t kshift = b == 16u ? 2u : (b == 4u ? 1u : 0u);
+            const uint32_t cap = cap1 * b;
+            // k_path_start writes every covered (pixel, slot) of the planes; only pixels this call does not cover
+            // (outside the viewport, other ranks' tiles) have to be cleared for k_accumulate_batch
+            if (partial) HIPCHK(c, hipMemsetAsync(T.contrib, 0, c->n_px * 16 * b, c->stream));
+            HIPCHK(c, hipMemsetAsync(T.cnt + RT_CNT_QUEUE_A, 0, 2 * sizeof(unsigned long long), c->stream));
+            HIPCHK(c, rtk_launch_path_start(c->stream, c->S, c->V, sh, P.flags, P.sample_first + s, P.seed, P.stream_id,
+                                            P.max_segments, T.contrib, (uint32_t)c->n_px, kshift, T.qa, T.cnt, RT_CNT_QUEUE_A, c->tune));
+            ++launches;
+            int in = RT_CNT_QUEUE_A, out = RT_CNT_QUEUE_B;
+            for (uint32_t seg = 1; seg < P.max_segments; ++seg) {
+                HIPCHK(c, hipMemsetAsync(T.cnt + out, 0, sizeof(unsigned long long), c->stream));
+                HIPCHK(c, rtk_launch_path_bounce(c->stream, c->S, P.flags, cap, seg + 1 == P.max_segments, T.contrib, (uint32_t)c->n_px,
+                                                 in == RT_CNT_QUEUE_A ? T.qa : T.qb, in == RT_CNT_QUEUE_A ? T.qb : T.qa,
+                                                 T.cnt, in, out, c->tune));
+                ++launches;
+                int tmp = in; in = out; out = tmp;
+            }
+            HIPCHK(c, rtk_launch_accumulate_batch(c->stream, T.accum, T.contrib, c->n_px, b));
+        }
+        *accum_samples += P.spp;
+        HIPCHK(c, rtk_launch_resolve(c->stream, T.accum, T.rgba, c->n_px, 0.0f, *accum_samples));
+    }
+    *launches_out = launches;
     return RT_OK;
 }
 
 int rt_render(rt_ctx *c, const rt_render_params *params) {
     if (!c) return RT_ERR_ARG;
     rt_render_params P;
-    std::memset(&P, 0, sizeof P);
-    if (params) {
-        if (params->struct_size != sizeof(rt_render_params)) return fail(c, RT_ERR_ARG, "rt_render: struct_size mismatch");
-        P = *params;
-    }
-    if (!c->has_scene || !c->has_view) return RT_NOT_READY;   // src/node.rs:52-56: skip silently
-    if (P.shard_count == 0) P.shard_count = 1;
-    // default tile: 64 px when tiles are what ranks own (SURVEY 8e), 32 px when they are only k_stream's unit of work
-    // distribution over the XCD queues (tools/tile_sweep.py: 16 / 32 / 64 / 128 / 256 px: 0.82 / 0.79 / 0.80 / 0.81 / 0.89 ms)
-    if (P.tile_size == 0) P.tile_size = P.shard_count > 1 ? 64 : 32;
-    if (P.tile_size % RT_WORK_TILE != 0 || P.tile_size > 4096) return fail(c, RT_ERR_ARG, "rt_render: tile_size must be a multiple of 16");
-    if (P.shard_count == 0) P.shard_count = 1;
-    if (P.shard_rank >= P.shard_count) return fail(c, RT_ERR_ARG, "rt_render: shard_rank >= shard_count");
+    RtShardDev sh{};
+    bool partial = false;
+    int rc = check_params(c, params, P, sh, partial);
+    if (rc != RT_OK) return rc;
     HIPCHK(c, hipSetDevice(c->device));
 
-    RtShardDev sh;
-    sh.rank = P.shard_rank; sh.count = P.shard_count; sh.tile = P.tile_size;
-    sh.tiles_x = (c->V.vw + sh.tile - 1) / sh.tile;
-    sh.tiles_y = (c->V.vh + sh.tile - 1) / sh.tile;
-    uint32_t n_tiles = sh.tiles_x * sh.tiles_y;
-    sh.n_owned = n_tiles > sh.rank ? (n_tiles - sh.rank + sh.count - 1) / sh.count : 0;
-
-    // Pixels this call does not cover (outside the viewport, other ranks' tiles) must read as
-    // cleared; clear only when the coverage changes.
-    bool partial = sh.count > 1 || c->V.vw != c->V.width || c->V.vh != c->V.height;
-    uint64_t sig = 1ull | (((uint64_t)sh.rank << 1) ^ ((uint64_t)sh.count << 17) ^ ((uint64_t)sh.tile << 33) ^
-                   ((uint64_t)c->V.vx << 5) ^ ((uint64_t)c->V.vy << 21) ^ ((uint64_t)c->V.vw << 37) ^
-                   ((uint64_t)c->V.vh << 49) ^ (partial ? 0x8000000000000000ull : 0ull));
-    bool path = (P.flags & RT_FLAG_PATH_TRACE) != 0;
-    for (int k = 0; k < 3; ++k)      // a camera beyond the wide step's coordinate range: binary tree (rt_layout.h)
-        if (!(std::fabs(c->V.pos[k]) < RT_WIDE_COORD_MAX)) P.flags |= RT_FLAG_BINARY_TREE;
-    if (sig != c->coverage_sig) {
-        int rc = clear_outputs(c);
+    RenderTargets T{};
+    T.rgba = c->d_rgba; T.accum = c->d_accum; T.t = c->d_t; T.prim = c->d_prim; T.cnt = c->d_cnt;
+    // Pixels this call does not cover (outside the viewport, other ranks' tiles) must read as cleared; clear only
+    // when the coverage changes.
+    const uint32_t cov[8] = {sh.rank, sh.count, sh.tile, c->V.vx, c->V.vy, c->V.vw, c->V.vh, partial ? 1u : 0u};
+    if (!c->coverage_valid || std::memcmp(cov, c->coverage, sizeof cov) != 0) {
+        rc = clear_outputs(c, T);
         if (rc != RT_OK) return rc;
-        c->coverage_sig = sig;
+        std::memcpy(c->coverage, cov, sizeof cov);
+        c->coverage_valid = true;
         c->accum_samples = 0;   // coverage changed: accumulation restarts (intent of src/scene.rs:94-96)
         HIPCHK(c, hipMemsetAsync(c->d_accum, 0, c->n_px * 16, c->stream));
     }
-    HIPCHK(c, hipMemsetAsync(c->d_cnt, 0, RT_CNT_N * sizeof(unsigned long long), c->stream));
+    if (P.flags & RT_FLAG_PATH_TRACE) {
+        T.max_batch = c->tune_sample_batch;
+        T.q_cap = (size_t)64 << 20;                      // at most 64 M queued paths
+        const uint32_t batch = batch_of(c, T, P.spp);
+        rc = ensure_queues(c, batch);
+        if (rc != RT_OK) return rc;
+        T.q_cap = c->q_capacity;
+        T.max_batch = std::min(c->tune_sample_batch, c->contrib_planes);
+        T.qa = queue_view(c->q[0], c->q_capacity); T.qb = queue_view(c->q[1], c->q_capacity);
+        T.contrib = c->d_contrib;
+        if (!(P.flags & RT_FLAG_ACCUMULATE) || c->accum_dirty) {
+            HIPCHK(c, hipMemsetAsync(c->d_accum, 0, c->n_px * 16, c->stream));
+            c->accum_samples = 0;
+            c->accum_dirty = false;
+        }
+    }
 
-    bool timed = (P.flags & RT_FLAG_TIME_KERNELS) != 0;
+    const bool timed = (P.flags & RT_FLAG_TIME_KERNELS) != 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     if (timed) {
         if (c->ev_used + 2 > c->ev.size()) {
@@ -816,68 +920,123 @@ int rt_render(rt_ctx *c, const rt_render_params *params) {
             }
         }
         ev0 = c->ev[c->ev_used]; ev1 = c->ev[c->ev_used + 1];
+        HIPCHK(c, hipEventRecord(ev0, c->stream));
     }
-
     uint32_t launches = 0;
-    if (!path) {
-        if (timed) HIPCHK(c, hipEventRecord(ev0, c->stream));
-        HIPCHK(c, rtk_launch_primary(c->stream, c->S, c->V, sh, P.flags, c->d_rgba, c->d_prim, c->d_t, c->d_cnt, c->tune));
-        launches = 1;
-        if (timed) HIPCHK(c, hipEventRecord(ev1, c->stream));
-    } else {
-        if (P.spp == 0) P.spp = 1;
-        if (P.max_segments == 0) P.max_segments = 4;   // reference shape: 4 segments (wgsl:185)
-        // samples are traced 16 or 4 at a time where there are that many (rt_kernels.hip k_path_start): one start launch
-        // and one launch per bounce for k x k samples of every pixel.  Bounded by 64 M queued paths and by
-        // RT_TUNE_SAMPLE_BATCH (1 = one launch per sample).
-        if (c->n_px > ((size_t)1 << 26)) return fail(c, RT_ERR_ARG, "rt_render: path tracing supports at most 2^26 pixels");
-        auto batch_of = [&](uint32_t left) {
-            uint32_t k2 = 1;
-            for (uint32_t cand : {4u, 16u})
-                if (cand <= left && cand <= c->tune_sample_batch && c->n_px * cand <= ((size_t)64 << 20) &&
-                    ((uint64_t)c->V.width << (cand == 4u ? 1 : 2)) * ((uint64_t)c->V.height << (cand == 4u ? 1 : 2)) <= (1ull << 31)) k2 = cand;
-            return k2;
-        };
-        const uint32_t batch = batch_of(P.spp);
-        int rc = ensure_queues(c, batch);
-        if (rc != RT_OK) return rc;
-        if (!(P.flags & RT_FLAG_ACCUMULATE) || c->accum_dirty) {
-            HIPCHK(c, hipMemsetAsync(c->d_accum, 0, c->n_px * 16, c->stream));
-            c->accum_samples = 0;
-            c->accum_dirty = false;
-        }
-        RtPathQueue qa = queue_view(c->q[0], c->q_capacity), qb = queue_view(c->q[1], c->q_capacity);
-        uint32_t cap1 = (uint32_t)((size_t)rtk_primary_blocks(sh) * RT_BLOCK);
-        if (cap1 > c->n_px) cap1 = (uint32_t)c->n_px;
-        if (timed) HIPCHK(c, hipEventRecord(ev0, c->stream));
-        for (uint32_t s = 0, b = 0; s < P.spp; s += b) {
-            b = batch_of(P.spp - s);                       // 16, 4 or 1 samples of every pixel in this round of launches
-            const uint32_t kshift = b == 16u ? 2u : (b == 4u ? 1u : 0u);
-            const uint32_t cap = cap1 * b;
-            // k_path_start writes every covered (pixel, slot) of the planes; only pixels this call does not cover
-            // (outside the viewport, other ranks' tiles) have to be cleared for k_accumulate_batch
-            if (partial) HIPCHK(c, hipMemsetAsync(c->d_contrib, 0, c->n_px * 16 * b, c->stream));
-            HIPCHK(c, hipMemsetAsync(c->d_cnt + RT_CNT_QUEUE_A, 0, 2 * sizeof(unsigned long long), c->stream));
-            HIPCHK(c, rtk_launch_path_start(c->stream, c->S, c->V, sh, P.flags, P.sample_first + s, P.seed, P.stream_id,
-                                            P.max_segments, c->d_contrib, (uint32_t)c->n_px, kshift, qa, c->d_cnt, RT_CNT_QUEUE_A, c->tune));
-            ++launches;
-            int in = RT_CNT_QUEUE_A, out = RT_CNT_QUEUE_B;
-            for (uint32_t seg = 1; seg < P.max_segments; ++seg) {
-                HIPCHK(c, hipMemsetAsync(c->d_cnt + out, 0, sizeof(unsigned long long), c->stream));
-                HIPCHK(c, rtk_launch_path_bounce(c->stream, c->S, P.flags, cap, seg + 1 == P.max_segments, c->d_contrib, (uint32_t)c->n_px,
-                                                 in == RT_CNT_QUEUE_A ? qa : qb, in == RT_CNT_QUEUE_A ? qb : qa,
-                                                 c->d_cnt, in, out, c->tune));
-                ++launches;
-                int tmp = in; in = out; out = tmp;
-            }
-            HIPCHK(c, rtk_launch_accumulate_batch(c->stream, c->d_accum, c->d_contrib, c->n_px, b));
-        }
-        c->accum_samples += P.spp;
-        HIPCHK(c, rtk_launch_resolve(c->stream, c->d_accum, c->d_rgba, c->n_px, 0.0f, c->accum_samples));
-        if (timed) HIPCHK(c, hipEventRecord(ev1, c->stream));
+    rc = launch_frame(c, P, sh, partial, T, &c->accum_samples, &launches);
+    if (rc != RT_OK) return rc;
+    if (timed) {
+        HIPCHK(c, hipEventRecord(ev1, c->stream));
+        c->ev_used += 2; c->counters.kernel_launches += launches;
     }
-    if (timed) { c->ev_used += 2; c->counters.kernel_launches += launches; }
     HIPCHK(c, hipMemcpyAsync(c->h_cnt, c->d_cnt, RT_CNT_N * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+    return RT_OK;
+}
+
+// ---- rt_render_static: the same frame, allocating nothing (include/rt_amd.h) -----------------------------------------
+// Outputs go to the caller's device buffers; the frame's scratch -- work-queue heads, counters, path queues, contribution
+// plane -- lives in the static device array of rt_kernels.hip, whose address on this context's device rt_create looked
+// up once (c->static_scratch).  No hipMalloc / hipFree / hipEventCreate on this path, first call included.
+namespace {
+constexpr size_t kStaticCntBytes = 4096;                                   // RT_CNT_N * 8 = 1152 B, rounded up
+constexpr size_t kStaticPathBytesPerPx = 2 * 11 * 4 + 16;                  // two queues of 11 dwords + one float4 plane
+constexpr size_t kStaticAlignSlack = 16 * 256;                             // every sub-buffer starts on a 256-B boundary
+constexpr size_t kStaticMaxPathPx = (RT_STATIC_SCRATCH_BYTES - kStaticCntBytes - kStaticAlignSlack) / kStaticPathBytesPerPx;
+}  // namespace
+int rt_render_static(rt_ctx *c, const rt_render_params *params, void *d_radiance, void *d_prim_ids, void *d_hit_t,
+                     void *d_accum, size_t n_pixels) {
+    if (!c) return RT_ERR_ARG;
+    rt_render_params P;
+    RtShardDev sh{};
+    bool partial = false;
+    int rc = check_params(c, params, P, sh, partial);
+    if (rc != RT_OK) return rc;
+    const bool path = (P.flags & RT_FLAG_PATH_TRACE) != 0;
+    if (!d_radiance || !d_prim_ids || !d_hit_t || (path && !d_accum))
+        return fail(c, RT_ERR_ARG, "rt_render_static: NULL output buffer (radiance, prim ids, hit t; accumulation when path tracing)");
+    if (n_pixels != c->n_px) return fail(c, RT_ERR_ARG, "rt_render_static: n_pixels must be width * height of the current view");
+    if (P.flags & RT_FLAG_TIME_KERNELS) return fail(c, RT_ERR_ARG, "rt_render_static: RT_FLAG_TIME_KERNELS creates events; time the stream yourself");
+    if (!c->static_scratch) return fail(c, RT_ERR_HIP, "rt_render_static: the static scratch array was not found on this device");
+    if (path && c->n_px > kStaticMaxPathPx) {
+        char msg[200];
+        snprintf(msg, sizeof msg, "rt_render_static: path tracing needs %zu B of scratch per pixel; the static array (%u MiB) holds frames of at most %zu pixels, this one has %zu",
+                 kStaticPathBytesPerPx, RT_STATIC_SCRATCH_BYTES >> 20, kStaticMaxPathPx, c->n_px);
+        return fail(c, RT_ERR_ARG, msg);
+    }
+    HIPCHK(c, hipSetDevice(c->device));
+
+    RenderTargets T{};
+    T.rgba = (float *)d_radiance; T.prim = (uint32_t *)d_prim_ids; T.t = (float *)d_hit_t; T.accum = (float *)d_accum;
+    unsigned char *base = (unsigned char *)c->static_scratch;      // the device address, never the symbol
+    T.cnt = (unsigned long long *)base;
+    if (path) {
+        size_t off = kStaticCntBytes;
+        auto take = [&](size_t bytes) { void *p = base + off; off = (off + bytes + 255) & ~(size_t)255; return p; };
+        QueueMem q[2];
+        for (int i = 0; i < 2; ++i) { q[i].f = (float *)take(c->n_px * 9 * 4); q[i].u = (uint32_t *)take(c->n_px * 2 * 4); }
+        T.contrib = (float *)take(c->n_px * 16);
+        if (off > RT_STATIC_SCRATCH_BYTES) return fail(c, RT_ERR_ARG, "rt_render_static: frame does not fit the static scratch array");
+        T.qa = queue_view(q[0], c->n_px); T.qb = queue_view(q[1], c->n_px);
+        T.q_cap = c->n_px; T.max_batch = 1;               // one sample per launch: same sums, bit for bit
+        if (!(P.flags & RT_FLAG_ACCUMULATE)) {
+            HIPCHK(c, hipMemsetAsync(T.accum, 0, c->n_px * 16, c->stream));
+            c->static_accum_samples = 0;
+        }
+    }
+    // the caller's buffers carry no history the library knows of: pixels this call does not cover are cleared every time
+    if (partial) { rc = clear_outputs(c, T); if (rc != RT_OK) return rc; }
+    uint32_t launches = 0;
+    rc = launch_frame(c, P, sh, partial, T, &c->static_accum_samples, &launches);
+    if (rc != RT_OK) return rc;
+    HIPCHK(c, hipMemcpyAsync(c->h_cnt, T.cnt, RT_CNT_N * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+    return RT_OK;
+}
+
+// ---- multi-GPU tile exchange -----------------------------------------------------------------------------
+static int shard_of(rt_ctx *c, uint32_t rank, uint32_t count, uint32_t tile, RtShardDev &sh, const char *who) {
+    if (!c->has_view || !c->d_rgba) return RT_NOT_READY;
+    if (count == 0) count = 1;
+    if (tile == 0) tile = 64;
+    if (tile % RT_WORK_TILE != 0 || tile > 4096 || rank >= count) return fail(c, RT_ERR_ARG, who);
+    sh.rank = rank; sh.count = count; sh.tile = tile;
+    sh.tiles_x = (c->V.vw + tile - 1) / tile;
+    sh.tiles_y = (c->V.vh + tile - 1) / tile;
+    const uint32_t n_tiles = sh.tiles_x * sh.tiles_y;
+    sh.n_owned = n_tiles > rank ? (n_tiles - rank + count - 1) / count : 0;
+    return RT_OK;
+}
+int rt_tile_slot_bytes(rt_ctx *c, uint32_t shard_count, uint32_t tile_size, size_t *bytes) {
+    if (!c || !bytes) return RT_ERR_ARG;
+    RtShardDev sh{};
+    int rc = shard_of(c, 0, shard_count, tile_size, sh, "rt_tile_slot_bytes: bad shard_count / tile_size");
+    if (rc != RT_OK) return rc;
+    *bytes = (size_t)sh.n_owned * sh.tile * sh.tile * 16;     // rank 0 owns the most tiles
+    return RT_OK;
+}
+int rt_pack_tiles(rt_ctx *c, uint32_t shard_rank, uint32_t shard_count, uint32_t tile_size, void *d_packed, size_t bytes) {
+    if (!c || !d_packed) return RT_ERR_ARG;
+    RtShardDev sh{};
+    int rc = shard_of(c, shard_rank, shard_count, tile_size, sh, "rt_pack_tiles: bad shard_rank / shard_count / tile_size");
+    if (rc != RT_OK) return rc;
+    if (bytes < (size_t)sh.n_owned * sh.tile * sh.tile * 16) return fail(c, RT_ERR_ARG, "rt_pack_tiles: buffer smaller than this rank's tiles");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, rtk_launch_tile_pack(c->stream, c->d_rgba, (float *)d_packed, c->V, sh));
+    return RT_OK;
+}
+int rt_unpack_tiles(rt_ctx *c, uint32_t first_rank, uint32_t n_ranks, uint32_t shard_count, uint32_t tile_size,
+                    const void *d_packed, size_t slot_bytes) {
+    if (!c || !d_packed) return RT_ERR_ARG;
+    if (n_ranks == 0) return RT_OK;
+    RtShardDev sh{};
+    int rc = shard_of(c, first_rank, shard_count, tile_size, sh, "rt_unpack_tiles: bad first_rank / shard_count / tile_size");
+    if (rc != RT_OK) return rc;
+    if ((uint64_t)first_rank + n_ranks > sh.count) return fail(c, RT_ERR_ARG, "rt_unpack_tiles: first_rank + n_ranks > shard_count");
+    const uint32_t n_tiles = sh.tiles_x * sh.tiles_y;
+    const size_t need = (size_t)((n_tiles + sh.count - 1) / sh.count) * sh.tile * sh.tile * 16;
+    if (slot_bytes < need || slot_bytes % 16 != 0) return fail(c, RT_ERR_ARG, "rt_unpack_tiles: slot_bytes smaller than rt_tile_slot_bytes (or not a multiple of 16)");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, rtk_launch_tile_unpack(c->stream, c->d_rgba, (const float *)d_packed, slot_bytes / 16, c->V, sh.tile, sh.tiles_x, n_tiles,
+                                     sh.count, first_rank, n_ranks));
     return RT_OK;
 }
 
@@ -938,6 +1097,22 @@ int rt_read_bgra8_srgb(rt_ctx *c, uint8_t *bgra, size_t n_bytes) {
     if (!c->d_bgra) HIPCHK(c, hipMalloc((void **)&c->d_bgra, c->n_px * 4));
     HIPCHK(c, rtk_launch_encode_bgra8(c->stream, c->d_rgba, c->d_bgra, c->n_px));
     return read_back(c, bgra, c->d_bgra, c->n_px * 4, n_bytes, "");
+}
+
+int rt_encode_bgra8_srgb(rt_ctx *c, const float *rgba, size_t n_pixels, uint8_t *bgra) {
+    if (!c || (n_pixels && (!rgba || !bgra))) return RT_ERR_ARG;
+    if (n_pixels == 0) return RT_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    void *d_in = nullptr, *d_out = nullptr;
+    hipError_t e = hipMalloc(&d_in, n_pixels * 16);
+    if (e == hipSuccess) e = hipMalloc(&d_out, n_pixels * 4);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_in, rgba, n_pixels * 16, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = rtk_launch_encode_bgra8(c->stream, (const float *)d_in, (uint8_t *)d_out, n_pixels);
+    if (e == hipSuccess) e = hipMemcpyAsync(bgra, d_out, n_pixels * 4, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    free_dev(d_in); free_dev(d_out);
+    if (e != hipSuccess) return fail(c, e == hipErrorOutOfMemory ? RT_ERR_OOM : RT_ERR_HIP, "rt_encode_bgra8_srgb", e);
+    return RT_OK;
 }
 
 int rt_device_buffers(rt_ctx *c, void **d_radiance, void **d_prim, void **d_accum) {

@@ -66,4 +66,14 @@ hipError_t rtk_launch_resolve(hipStream_t st, const float *accum, float *rgba, s
                               uint32_t total_samples);
 hipError_t rtk_launch_accumulate_batch(hipStream_t st, float *accum, const float *contrib, size_t n_px, uint32_t batch);
 hipError_t rtk_launch_encode_bgra8(hipStream_t st, const float *rgba, uint8_t *bgra, size_t n_px);
+// multi-GPU tile exchange: this rank's owned shard tiles packed contiguously (tile*tile float4 per tile, owned-tile
+// order), and the scatter of n_src ranks' packed tiles (slot s = rank first_rank + s, slots slot_stride_px float4 apart)
+hipError_t rtk_launch_tile_pack(hipStream_t st, const float *frame, float *packed, const RtViewDev &V, const RtShardDev &sh);
+hipError_t rtk_launch_tile_unpack(hipStream_t st, float *frame, const float *packed, size_t slot_stride_px, const RtViewDev &V,
+                                  uint32_t tile, uint32_t tiles_x, uint32_t n_tiles, uint32_t count, uint32_t first_rank, uint32_t n_src);
+
+// rt_render_static: the address, on the CURRENT device, of the file-scope scratch array (RT_STATIC_SCRATCH_BYTES)
+#define RT_STATIC_SCRATCH_BYTES (32u << 20)
+hipError_t rtk_static_scratch_address(void **ptr);
+
 hipError_t rtk_launch_fill_u32(hipStream_t st, uint32_t *p, uint32_t value, size_t n);

@@ -80,6 +80,14 @@ __device__ __forceinline__ bool ray_tri(f3 o, f3 d, f3 a, f3 ab, f3 ac, float &d
     return det >= 1e-6f && dst >= 0.0f && u >= 0.0f && v >= 0.0f && w >= 0.0f;
 }
 
+// A ray with a NaN in its origin or direction misses everything in the reference's loop (every compare of wgsl:137 is
+// false; a sphere's discriminant is NaN).  It is ended before it starts: the quantised wide step drops NaN operands
+// through min/max and would walk the WHOLE tree for it (a multi-second kernel on the big scenes).  Such rays
+// come from zero-length vertex normals (shadow-ray origin) or a degenerate world_from_clip (0/0 directions).
+__device__ __forceinline__ bool ray_has_nan(f3 o, f3 d) {
+    return o.x != o.x || o.y != o.y || o.z != o.z || d.x != d.x || d.y != d.y || d.z != d.z;
+}
+
 struct q4 { float x, y, z, w; };
 // ---- extension: ray / analytic sphere (build-defined; oracle orc_ray_sphere, same operation order) ----------
 __device__ __forceinline__ bool ray_sphere(f3 o, f3 d, f3 c, float r, float &dst) {
@@ -261,8 +269,9 @@ __device__ __forceinline__ void traverse(const RtSceneDev &S, f3 o, f3 d, uint32
     prv_int *ovf = (prv_int *)ovf_mem;
     const uint32_t n_all = (uint32_t)__builtin_popcountll(__ballot(true));
     int sp = 0;
-    int cur = 0;
-    uint32_t n_done = 0;
+    int cur = ray_has_nan(o, d) ? RT_DONE : 0;
+    uint32_t n_done = (uint32_t)__builtin_popcountll(__ballot(cur == RT_DONE));
+    if (n_done == n_all) return;
     uint32_t rec = 0xFFFFFFFFu;           // the accepted record: one register instead of hit flag + tri + mesh
     do {
         const unsigned long long m_node = __ballot(cur >= 0);
@@ -337,6 +346,7 @@ __device__ __forceinline__ void traverse_packet(const RtSceneDev &S, f3 o, f3 d,
                                                 int *wstk, Hit &h, Cnt &c) {
     h.hit = false; h.t = RT_INF; h.u = 0.0f; h.v = 0.0f; h.seq = 0xFFFFFFFFu; h.tri = 0xFFFFFFFFu; h.mesh = 0;
     if (S.n_nodes == 0) return;
+    alive = alive && !ray_has_nan(o, d);
     if (__ballot(alive) == 0ull) return;
     const f3 inv = F3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
     const bool lane0 = (threadIdx.x & 63u) == 0u;
@@ -703,7 +713,7 @@ __device__ __forceinline__ void stream_body(
                     o = add(point, scl(normal, 1e-3f)); d = F3(0.0f, 1.0f, 0.0f);
                     inv = ray_inv<WIDE>(d);
                     t = RT_INF; seq = 0xFFFFFFFFu; rec = 0xFFFFFFFFu;
-                    cur = 0; sp = 0;
+                    cur = ray_has_nan(o, d) ? RT_DONE : 0; sp = 0;
                     state = 2;
                     ++n_shadow;
                 }
@@ -756,7 +766,7 @@ __device__ __forceinline__ void stream_body(
                         ray_gen(V, px, py, o, d);
                         inv = ray_inv<WIDE>(d);
                         t = RT_INF; seq = 0xFFFFFFFFu; rec = 0xFFFFFFFFu;
-                        cur = S.n_nodes ? 0 : RT_DONE; sp = 0;
+                        cur = S.n_nodes && !ray_has_nan(o, d) ? 0 : RT_DONE; sp = 0;
                         idx = py * V.width + px;
                         state = 1;
                         ++n_primary;
@@ -1308,11 +1318,18 @@ __global__ void k_resolve(const float4 *__restrict__ accum, float4 *__restrict__
 }
 
 // ---- presentation: clamp + sRGB encode to BGRA8 (src/pipeline.rs:56-60) ------------------------------
-__device__ __forceinline__ float srgb_oetf(float x) {
-    if (!(x > 0.0f)) return 0.0f;
-    if (x >= 1.0f) return 1.0f;
-    if (x <= 0.0031308f) return x * 12.92f;
-    return 1.055f * powf(x, 1.0f / 2.4f) - 0.055f;
+// Byte work, so it is exact: a colour byte = round(255 * srgb_oetf(x)) = the number of linear-space thresholds <= x
+// (rt_srgb_table.h: for k = 1..255 the smallest binary32 x whose byte is >= k, exactly rounded from the OETF by
+// tools/gen_srgb_table.py).  Float compares only -- the oracle counts over the same values and the bytes are identical
+// (a powf here against a pow in double there differed by 1 LSB on ~1 % of the bytes).  NaN and x <= 0 give 0, x >= 1
+// gives 255.  The table sits in LDS (1 KiB per block): eight dependent ds_reads per channel, no divergent constant fetch.
+#define RT_SRGB_TABLE_QUAL static __device__ const
+#include "rt_srgb_table.h"
+__device__ __forceinline__ uint32_t srgb_byte(const float *tab, float x) {
+    uint32_t n = 0;
+#pragma unroll
+    for (uint32_t step = 128u; step; step >>= 1) n += tab[n + step - 1u] <= x ? step : 0u;
+    return n;
 }
 __device__ __forceinline__ uint32_t unorm8(float x) {
     if (!(x > 0.0f)) x = 0.0f;
@@ -1320,12 +1337,55 @@ __device__ __forceinline__ uint32_t unorm8(float x) {
     return (uint32_t)floorf(x * 255.0f + 0.5f);
 }
 __global__ void k_encode_bgra8(const float4 *__restrict__ rgba, uint32_t *__restrict__ bgra, size_t n) {
+    __shared__ float tab[256];
+    for (uint32_t k = threadIdx.x; k < 256u; k += blockDim.x) tab[k] = k < 255u ? __uint_as_float(RT_SRGB_THRESHOLD_BITS[k]) : RT_INF;
+    __syncthreads();
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     size_t stride = (size_t)gridDim.x * blockDim.x;
     for (; i < n; i += stride) {
         float4 c = rgba[i];
-        bgra[i] = unorm8(srgb_oetf(c.z)) | (unorm8(srgb_oetf(c.y)) << 8) | (unorm8(srgb_oetf(c.x)) << 16) |
-                  (unorm8(c.w) << 24);
+        bgra[i] = srgb_byte(tab, c.z) | (srgb_byte(tab, c.y) << 8) | (srgb_byte(tab, c.x) << 16) | (unorm8(c.w) << 24);
+    }
+}
+
+
+// ---- multi-GPU tile exchange: this rank's shard tiles, packed ---------------------------------------
+// Rank r owns the shard tiles g = r + k * count (k = 0, 1, ...: its owned-tile ordinal; g = ty * tiles_x + tx over the
+// covered rect, as pixel_of_thread / pixel_of_region deal them).  Packed layout: tile k occupies tile*tile float4
+// slots, row-major inside the tile; slots outside the covered rect (edge tiles) are written as zeros and ignored by
+// the unpack.  One thread per float4, consecutive threads = consecutive pixels of a tile row: both sides coalesce.
+__global__ void k_tile_pack(const float4 *__restrict__ frame, float4 *__restrict__ packed, RtViewDev V, RtShardDev sh) {
+    const uint32_t per_tile = sh.tile * sh.tile;
+    const size_t n = (size_t)sh.n_owned * per_tile;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        const uint32_t k = (uint32_t)(i / per_tile), w = (uint32_t)(i % per_tile);
+        const uint32_t g = sh.rank + k * sh.count;
+        const uint32_t x = (g % sh.tiles_x) * sh.tile + w % sh.tile, y = (g / sh.tiles_x) * sh.tile + w / sh.tile;
+        float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (x < V.vw && y < V.vh) v = frame[(size_t)(V.vy + y) * V.width + (V.vx + x)];
+        packed[i] = v;
+    }
+}
+// The other direction, for n_src ranks at once: slot s of `packed` (slot_stride float4 apart) holds the packed tiles
+// of rank first_rank + s; every pixel of those tiles goes to its place in `frame`.
+__global__ void k_tile_unpack(float4 *__restrict__ frame, const float4 *__restrict__ packed, size_t slot_stride, RtViewDev V,
+                              uint32_t tile, uint32_t tiles_x, uint32_t n_tiles, uint32_t count, uint32_t first_rank, uint32_t n_src) {
+    const uint32_t per_tile = tile * tile;
+    const uint32_t max_owned = (n_tiles + count - 1u) / count;
+    const size_t per_rank = (size_t)max_owned * per_tile;
+    const size_t n = per_rank * n_src;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        const uint32_t s = (uint32_t)(i / per_rank);
+        const size_t j = i % per_rank;
+        const uint32_t k = (uint32_t)(j / per_tile), w = (uint32_t)(j % per_tile);
+        const uint32_t g = first_rank + s + k * count;
+        if (g >= n_tiles) continue;
+        const uint32_t x = (g % tiles_x) * tile + w % tile, y = (g / tiles_x) * tile + w / tile;
+        if (x < V.vw && y < V.vh) frame[(size_t)(V.vy + y) * V.width + (V.vx + x)] = packed[(size_t)s * slot_stride + j];
     }
 }
 
@@ -1431,6 +1491,37 @@ hipError_t rtk_launch_encode_bgra8(hipStream_t st, const float *rgba, uint8_t *b
     if (n_px == 0) return hipSuccess;
     hipLaunchKernelGGL(k_encode_bgra8, dim3(stream_grid(n_px)), dim3(256), 0, st, (const float4 *)rgba, (uint32_t *)bgra, n_px);
     return hipGetLastError();
+}
+
+hipError_t rtk_launch_tile_pack(hipStream_t st, const float *frame, float *packed, const RtViewDev &V, const RtShardDev &sh) {
+    const size_t n = (size_t)sh.n_owned * sh.tile * sh.tile;
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_tile_pack, dim3(stream_grid(n)), dim3(256), 0, st, (const float4 *)frame, (float4 *)packed, V, sh);
+    return hipGetLastError();
+}
+hipError_t rtk_launch_tile_unpack(hipStream_t st, float *frame, const float *packed, size_t slot_stride_px, const RtViewDev &V,
+                                  uint32_t tile, uint32_t tiles_x, uint32_t n_tiles, uint32_t count, uint32_t first_rank, uint32_t n_src) {
+    const size_t n = (size_t)((n_tiles + count - 1u) / count) * tile * tile * n_src;
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_tile_unpack, dim3(stream_grid(n)), dim3(256), 0, st, (float4 *)frame, (const float4 *)packed, slot_stride_px, V,
+                       tile, tiles_x, n_tiles, count, first_rank, n_src);
+    return hipGetLastError();
+}
+
+// ---- static scratch for rt_render_static (callers that cannot allocate: include/rt_amd.h) -------------------------
+// The work-queue heads, counters, path queues and contribution plane of ONE frame, in a file-scope device array instead
+// of hipMalloc'ed memory.  Every GPU the library runs on holds its own copy at its own address for the life of the
+// process; `rt_static_scratch` below is only the host-side handle of the symbol -- host code never passes it to a kernel,
+// it asks each device for the array's address once (rtk_static_scratch_address, called by rt_create with that device
+// current) and uses that pointer from then on.
+static __device__ __align__(256) unsigned char rt_static_scratch[RT_STATIC_SCRATCH_BYTES];
+hipError_t rtk_static_scratch_address(void **ptr) {
+    void *p = nullptr;
+    hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(rt_static_scratch));
+    if (e != hipSuccess) return e;
+    if (!p) return hipErrorInvalidSymbol;
+    *ptr = p;
+    return hipSuccess;
 }
 hipError_t rtk_launch_fill_u32(hipStream_t st, uint32_t *p, uint32_t value, size_t n) {
     if (n == 0) return hipSuccess;

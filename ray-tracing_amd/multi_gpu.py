@@ -84,26 +84,82 @@ def wrap_device_buffer(ptr, n_floats, device_index):
     return torch.as_tensor(_Ptr(), device=f"cuda:{device_index}")
 
 
+def _tiles_of(vw, vh, tile):
+    return (vw + tile - 1) // tile, (vh + tile - 1) // tile
+
+
+def tile_slot_floats(vw, vh, tile, count):
+    """Floats in one rank's packed-tile message, sized for the rank that owns the most tiles (rank 0): what
+    rt_tile_slot_bytes returns, / 4.  (vw, vh) = the covered rect."""
+    tx, ty = _tiles_of(vw, vh, tile)
+    return ((tx * ty + count - 1) // count) * tile * tile * 4
+
+
+def pack_tiles_host(frame, rect, tile, count, rank):
+    """The packed layout of rt_pack_tiles / k_tile_pack restated on the host (numpy): rank's owned tiles g = rank,
+    rank + count, ... (row-major over the covered rect = (x, y, w, h)) one after the other, tile*tile RGBA f32 each,
+    zeros where an edge tile leaves the rect.  Used by the gloo rehearsal / CPU tests, and the GPU tests hold the HIP
+    kernel to it byte for byte.  frame: (H, W, 4) float32."""
+    vx, vy, vw, vh = rect
+    tx, ty = _tiles_of(vw, vh, tile)
+    owned = range(rank, tx * ty, count)
+    out = np.zeros((len(owned), tile, tile, 4), np.float32)
+    for k, g in enumerate(owned):
+        x0, y0 = (g % tx) * tile, (g // tx) * tile
+        w, h = min(tile, vw - x0), min(tile, vh - y0)
+        out[k, :h, :w] = frame[vy + y0:vy + y0 + h, vx + x0:vx + x0 + w]
+    return out.reshape(-1)
+
+
+def unpack_tiles_host(frame, slots, rect, tile, count, ranks):
+    """The scatter of rt_unpack_tiles / k_tile_unpack on the host: slots[i] holds the packed tiles of ranks[i]."""
+    vx, vy, vw, vh = rect
+    tx, ty = _tiles_of(vw, vh, tile)
+    for slot, rank in zip(slots, ranks):
+        owned = range(rank, tx * ty, count)
+        tiles = np.asarray(slot[: len(owned) * tile * tile * 4]).reshape(len(owned), tile, tile, 4)
+        for k, g in enumerate(owned):
+            x0, y0 = (g % tx) * tile, (g // tx) * tile
+            w, h = min(tile, vw - x0), min(tile, vh - y0)
+            frame[vy + y0:vy + y0 + h, vx + x0:vx + x0 + w] = tiles[k, :h, :w]
+    return frame
+
+
 class TileGather:
-    """Packed-tile gather to rank 0.  Every rank holds a full-frame tensor (H*W*C floats) in which only its own
-    tiles are meaningful; combine() leaves the complete frame in rank 0's tensor.  Index tensors are built once."""
+    """Packed-tile gather to rank 0: every rank packs the tiles it rendered into one contiguous message,
+    ONE dist.gather moves the N - 1 messages straight to rank 0 (RCCL: one send per peer, one xGMI link each), and rank 0
+    scatters them into its frame.  No per-frame Python loop over ranks and no full-frame copy.
 
-    def __init__(self, width, height, tile, world, rank, channels=4, device="cpu", group=None):
+    Device path (ctx given): rt_pack_tiles / rt_unpack_tiles -- two HIP kernels on the context's stream, the packed
+    buffers are torch tensors on that device, and combine() must be called with that stream current (the caller runs its
+    loop under torch.cuda.stream(s) with ctx.set_stream(s.cuda_stream)), so pack -> gather -> unpack are ordered.
+    Host path (ctx None; gloo rehearsal and CPU tests): the same layout through pack_tiles_host / unpack_tiles_host on a
+    host frame the caller passes in."""
+
+    def __init__(self, width, height, tile, world, rank, ctx=None, device="cpu", rect=None, group=None):
         import torch
-        self.world, self.rank, self.channels, self.group = world, rank, channels, group
-        owner = tile_owner(width, height, tile, world).reshape(-1)
-        self.idx = [torch.from_numpy(np.flatnonzero(owner == r).astype(np.int64)).to(device) for r in range(world)]
-        self.n_max = max(int(i.numel()) for i in self.idx)          # gather wants equal sizes: pad to the largest share
-        self.send = torch.zeros(self.n_max * channels, dtype=torch.float32, device=device)
-        self.recv = [torch.zeros_like(self.send) for _ in range(world)] if rank == 0 else None
+        self.world, self.rank, self.tile, self.group, self.ctx = world, rank, tile, group, ctx
+        self.rect = tuple(rect) if rect is not None else (0, 0, width, height)
+        self.slot = tile_slot_floats(self.rect[2], self.rect[3], tile, world)
+        if ctx is not None:
+            assert ctx.tile_slot_bytes(world, tile) == self.slot * 4
+        self.send = torch.zeros(self.slot, dtype=torch.float32, device=device)
+        self.recv = torch.zeros(self.slot * world, dtype=torch.float32, device=device) if rank == 0 else None
+        self.recv_list = list(self.recv.view(world, self.slot).unbind(0)) if rank == 0 else None
 
-    def combine(self, frame):
+    def combine(self, frame=None):
+        """Device path: frame is ignored (the context's radiance buffer is source and destination).  Host path: frame is
+        this rank's (H, W, 4) float32 numpy array; rank 0's is completed in place and returned."""
+        import torch
         import torch.distributed as dist
-        px = frame.view(-1, self.channels)
-        mine = self.idx[self.rank]
-        self.send.view(-1, self.channels)[: mine.numel()].copy_(px.index_select(0, mine))
-        dist.gather(self.send, self.recv, dst=0, group=self.group)
-        if self.rank == 0:
-            for r in range(1, self.world):
-                px.index_copy_(0, self.idx[r], self.recv[r].view(-1, self.channels)[: self.idx[r].numel()])
+        if self.ctx is not None:
+            self.ctx.pack_tiles(self.rank, self.world, self.tile, self.send.data_ptr(), self.slot * 4)
+        else:
+            self.send.copy_(torch.from_numpy(np.resize(pack_tiles_host(frame, self.rect, self.tile, self.world, self.rank), self.slot)))
+        dist.gather(self.send, self.recv_list, dst=0, group=self.group)
+        if self.rank == 0 and self.world > 1:
+            if self.ctx is not None:   # every peer's tiles in one launch; rank 0's own tiles are already in place
+                self.ctx.unpack_tiles(1, self.world - 1, self.world, self.tile, self.recv.data_ptr() + self.slot * 4, self.slot * 4)
+            else:
+                unpack_tiles_host(frame, self.recv.view(self.world, self.slot)[1:].numpy(), self.rect, self.tile, self.world, range(1, self.world))
         return frame

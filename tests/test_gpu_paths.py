@@ -160,13 +160,26 @@ def test_tile_shards_partition_the_frame(count, tile):
 
 
 def test_presentation_bgra8_srgb():
+    """f2 (src/pipeline.rs:56-60): byte work, so the bytes are the oracle's, all of them -- on a rendered frame and on a
+    2^24-value sweep of [0, 1] plus the knee of the OETF, every byte threshold and its predecessor, NaN, < 0 and > 1."""
     app = default_app(64, 36)
     scene = app.prepare_meshinfo()
-    ctx, rgba, _, _ = gpu_render(app, scene, 0)
-    got = ctx.read_bgra8_srgb().astype(np.int16)
-    want = orc.encode_bgra8_srgb(rgba).astype(np.int16)
-    assert np.abs(got - want).max() <= 1          # powf on the device vs pow in double: at most 1 LSB at a rounding edge
-    assert (got != want).mean() < 0.01
+    ctx, rgba, _, _ = gpu_render(app, scene, rt.FLAG_SHADOW)
+    assert bitwise_equal(ctx.read_bgra8_srgb(), orc.encode_bgra8_srgb(rgba))
+    n = 1 << 24
+    x = np.empty((n + 4096, 4), np.float32)
+    x[:n, 0] = np.arange(n, dtype=np.float64) / n                                   # red: every k / 2^24
+    x[:n, 1] = np.random.default_rng(1).random(n, dtype=np.float32)                   # green: random
+    x[:n, 2] = (np.arange(n, dtype=np.float64) / n) ** 3                              # blue: dense near 0 (the linear piece)
+    x[:n, 3] = np.arange(n, dtype=np.float64)[::-1] / n                               # alpha: linear unorm8
+    import re
+    bits = np.array([int(v, 16) for v in re.findall(r"0x([0-9A-F]{8})u", open(os.path.join(HERE, "..", "oracle", "srgb_table.h")).read())], np.uint32)
+    t = bits.view(np.float32)
+    special = np.concatenate([t, np.nextafter(t, np.float32(-1)), np.nextafter(t, np.float32(2)),
+                              np.array([0.0, -0.0, -1.0, 1.0, 1.5, np.inf, -np.inf, np.nan, 0.0031308, np.nextafter(np.float32(0.0031308), np.float32(1)),
+                                        1e-45, 1e-30, 0.5, np.nextafter(np.float32(1), np.float32(0))], np.float32)])
+    x[n:] = np.resize(special, (4096, 1))
+    assert bitwise_equal(ctx.encode_bgra8_srgb(x), orc.encode_bgra8_srgb(x))
     ctx.close()
 
 

@@ -48,11 +48,23 @@ def _worker(rank, world, port, out):
     multi_gpu.combine_tiles(t)
     tiles_ok = t.numpy().tobytes() == full.tobytes()
     # the same tiles through the packed gather: rank 0 ends with the full frame, bit for bit
+    # (host packer: the layout the HIP kernels k_tile_pack / k_tile_unpack are held to in tests/test_gpu_round2.py)
     g2 = multi_gpu.TileGather(W, H, 16, world, rank)
-    t2 = torch.from_numpy(mine.copy()).reshape(-1)
-    g2.combine(t2)
+    f2 = mine.copy()
+    g2.combine(f2)
     if rank == 0:
-        tiles_ok = tiles_ok and t2.numpy().tobytes() == full.tobytes()
+        tiles_ok = tiles_ok and f2.tobytes() == full.tobytes()
+    # ... and in a viewport with ragged edge tiles, three tiles per row shared unevenly
+    rect = (5, 3, 40, 26)
+    inside = np.zeros((H, W), bool)
+    inside[3:29, 5:45] = True
+    ys, xs = np.mgrid[0:H, 0:W]
+    own_v = (((ys - 3) // 16) * 3 + (xs - 5) // 16) % world
+    mine_v = np.where((inside & (own_v == rank))[..., None], full, np.float32(0.0))
+    g3 = multi_gpu.TileGather(W, H, 16, world, rank, rect=rect)
+    g3.combine(mine_v)
+    if rank == 0:
+        tiles_ok = tiles_ok and mine_v.tobytes() == np.where(inside[..., None], full, np.float32(0.0)).tobytes()
 
     # --- samples: rank r renders samples [2r, 2r+2) with RNG stream id 0 (same stream, disjoint indices)
     acc, _ = orc.render_path(s, v, 2, 4, seed=3, sample_first=2 * rank, threads=1)

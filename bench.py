@@ -4,12 +4,13 @@
 Workload at N=1 (BASELINE.json configs[1]): synthetic 10k-sphere field,
 reference-faithful tessellation (ico(5): 7.2 M triangles + ground plane), 1920x1080, one primary
 ray per pixel + one shadow ray per hit.  A step = one frame through rt_render (C ABI).
-N>1: scene replicated, one process per GPU; --mode frames (default) gives every rank its own
-camera on an orbit (weak scaling, no data-path collective); --mode tiles shards ONE frame by
-64x64 screen tiles round-robin over the ranks and gathers every rank's packed tiles on rank 0 over RCCL
-(one xGMI link per peer; strong scaling); --mode samples (path-tracing workloads) gives every
-rank its own sample slice of ONE frame and combines the accumulation buffers with one all_reduce(sum)
-(weak scaling in samples: SURVEY 8e, BASELINE.json configs[4]).
+N>1: scene replicated, one process per GPU (launched by torch.distributed.run, or -- when WORLD_SIZE is not set --
+by this script itself, which starts N rank processes before anything touches a GPU).  --mode tiles (the default,
+BASELINE.json north_star / SURVEY 8e): ONE frame sharded by 64x64 screen tiles round-robin over the ranks, every rank
+packs its tiles with a HIP kernel and ONE gather over RCCL (one xGMI link per peer) brings them to rank 0, which
+scatters them into its frame with one more kernel: strong scaling.  --mode samples (path-tracing workloads): every
+rank its own sample slice of ONE frame, accumulation buffers combined by a direct reduce-scatter + gather (weak
+scaling in samples, configs[4]).  --mode frames: every rank its own camera on an orbit, no data-path collective.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` and
 `cpu_baseline` objects.  Never reads /root/reference.
@@ -103,19 +104,44 @@ def cpu_baseline(orc, scene, view, W, H, flags, target_seconds=15.0):
                        f"reference-shaped brute-force loop (oracle/rt_oracle.c), {dt:.1f} s"), perm[:n], rgba, prim
 
 
+def self_launch(n):
+    """`bench.py --gpus N` without a launcher: start N rank processes (one per GPU, RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_* in their environment) from THIS process, which has not touched a GPU and never will; rank 0's stdout is
+    the bench line."""
+    import socket
+    import subprocess
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    for pr in procs:
+        rc = max(rc, abs(pr.wait()))
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="sphere_field_10k_1080p_primary_shadow", choices=sorted(WORKLOADS))
-    ap.add_argument("--mode", default="frames", choices=["frames", "tiles", "samples"])
+    ap.add_argument("--mode", default="tiles", choices=["frames", "tiles", "samples"], help="N > 1 only; tiles = north_star's partitioning")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pipelined", action="store_true", help="skip the extra two-frames-in-flight measurement (N=1, after the timed region)")
+    ap.add_argument("--no-north-star", action="store_true", help="skip the extra 1M-triangle soup measurement (N=1, default workload, after the timed region)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--extra-flags", type=lambda v: int(v, 0), default=0,
                     help="experiments only: OR these RT_FLAG_* bits into every render (e.g. 0x100 = static grid, 0x200 = binary tree)")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args.gpus))
 
     import torch
     import torch.distributed as dist
@@ -151,8 +177,12 @@ def main():
     if WORKLOADS[args.workload][0] == "field_analytic":
         scene = rt.analytic_sphere_field(WORKLOADS[args.workload][1], WORKLOADS[args.workload][2])
     ctx = rt.Context(local_rank)
-    stream = torch.cuda.current_stream()
-    ctx.set_stream(stream.cuda_stream)        # kernels run on torch's stream: events below see them
+    # ONE stream for the library's kernels, torch's copies and the collectives' hand-over: a torch side stream (non-zero
+    # handle; the default stream's handle is 0, which rt_set_stream reads as "the context's own stream"), made current
+    # for the whole run so that render -> pack -> gather -> unpack are ordered without host synchronisation
+    stream = torch.cuda.Stream(device=local_rank)
+    torch.cuda.set_stream(stream)
+    ctx.set_stream(stream.cuda_stream)
     ctx.upload_scene(scene)                   # upload + BVH build, outside the timed region
     m, p = app.camera_view()
     ctx.set_view(m, p, W, H)
@@ -179,17 +209,14 @@ def main():
         alg_bytes = (cnt.node_visits * info.node_bytes + cnt.tri_tests * info.tri_bytes + cnt.mesh_aabb_tests * 32 +
                      cnt.rays_primary * 24 + hits * 80)
 
-    rad_t = None
+    gather = None
     if tiles:
-        d_rad, _, _ = ctx.device_buffers()
-
-        class _Ptr:   # wrap the library's radiance buffer as a torch tensor (no copy)
-            __cuda_array_interface__ = dict(shape=(H * W * 4,), typestr="<f4", data=(d_rad, False), version=2)
-        rad_t = torch.as_tensor(_Ptr(), device=f"cuda:{local_rank}")
-        frame_t = torch.empty_like(rad_t)   # combined frame; the library's buffer keeps only this rank's tiles
         from ray_tracing_amd import multi_gpu
         gloo = dist.get_backend() == "gloo"
-        gather = multi_gpu.TileGather(W, H, 64, world, rank, 4, "cpu" if gloo else f"cuda:{local_rank}")
+        # RCCL: pack / unpack are HIP kernels on the context's stream, the packed messages torch tensors on this device.
+        # gloo (one-GPU rehearsal only): gloo moves host tensors, so the frame is read back and the host restatement of
+        # the same packed layout is used.
+        gather = multi_gpu.TileGather(W, H, 64, world, rank, ctx=None if gloo else ctx, device="cpu" if gloo else f"cuda:{local_rank}")
 
     acc_t = None
     if samples:
@@ -216,14 +243,7 @@ def main():
                 rad_s.copy_(res)
         if tiles:
             # every rank sends its own tiles, packed, straight to rank 0: one xGMI link per peer, 1/N of a frame each
-            if gloo:                                          # rehearsal only: gloo moves host tensors
-                host = rad_t.cpu()
-                gather.combine(host)
-                if rank == 0:
-                    frame_t.copy_(host)
-            else:
-                frame_t.copy_(rad_t)
-                gather.combine(frame_t)
+            gather.combine(ctx.read_radiance() if gloo else None)
 
     for _ in range(args.warmup):
         step(flags)
@@ -255,18 +275,52 @@ def main():
         ms_per_step = dt / args.steps * 1e3
         value = total_rays * args.steps / dt / 1e6
         achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
-        traffic, pmc_extra = None, {}
+        # which kernel the flags select (rtk_launch_primary)
+        wide = bool(info.n_wide_nodes) and not (flags & rt.FLAG_BINARY_TREE)
+        if spp:
+            kernel = "k_path_start+k_path_bounce (whole frame)"
+        elif flags & rt.FLAG_BRUTE_FORCE or flags & rt.FLAG_STATIC_GRID:
+            kernel = "k_primary<false, false>"
+        elif flags & rt.FLAG_WAVE_TRAVERSAL:
+            kernel = "k_primary<false, true>"
+        else:
+            kernel = f"k_stream<false, {'true' if wide else 'false'}>"
+        # Counters of the committed PMC passes (profiles/pmc_traffic.json; rocprofv3 --pmc cannot run inside this process):
+        # quoted only for the workload AND the very kernel binary they were collected on -- the file records the kernel's
+        # symbol, registers, spills and the hash of the device code object (tools/kernel_resources.py); a library built
+        # from other kernel sources makes them stale, and stale counters are not printed.
+        traffic, valu, hbm_frac, pmc = None, None, None, {"measured_in_this_run": False}
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(tpath):
-            try:
-                tj = json.load(open(tpath))
-                if tj.get("workload") == args.workload:
-                    traffic = tj.get("hbm_bytes_per_launch")
-                    # VALU utilisation from the same committed PMC passes (north_star: "rocprof counters must show
-                    # achieved HBM GB/s and VALU utilisation"): not measured by this run, quoted from profiles/
-                    pmc_extra = {k: tj[k] for k in ("valu_busy", "valu_lanes_active", "pmc_source") if k in tj}
-            except Exception:
-                traffic, pmc_extra = None, {}
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import kernel_resources
+            tj = json.load(open(tpath))
+            now = kernel_resources.fingerprint(rt.LIB_PATH, tj.get("fingerprint_kernels", "k_stream"))
+            pmc["source"] = tj.get("pmc_source")
+            if tj.get("workload") != args.workload or tj.get("kernel") != kernel or world != 1:
+                pmc["quoted"] = False
+                pmc["why"] = "committed passes are for another workload / kernel / GPU count"
+            elif tj.get("fingerprint") != now:
+                pmc["quoted"] = False
+                pmc["stale"] = True
+                pmc["why"] = "librt_amd.so's device code differs from the one the passes were collected on: rerun profiles/pmc_passes.sh"
+            else:
+                pmc["quoted"] = True
+                traffic = tj.get("hbm_bytes_per_launch")
+                valu = {"busy": tj["valu_busy"], "lanes_active": tj["valu_lanes_active"],
+                        "frac": round(tj["valu_busy"] * tj["valu_lanes_active"], 4)}
+                if traffic and kernel_ms > 0:
+                    hbm_frac = round(traffic / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+        except Exception as ex:
+            pmc["quoted"] = False
+            pmc["why"] = f"no usable profiles/pmc_traffic.json: {str(ex)[:80]}"
+        # The bound: SURVEY 8d names HBM as the nominal roofline and `achieved`/`frac` keep that definition (ALGORITHMIC
+        # bytes -- every lane's node / record fetch, most of them served by L1 / L2 / Infinity Cache -- over kernel time),
+        # but the counters decide the label: VALU issue when the VALU pipes are busier than the memory side.
+        if valu is not None and hbm_frac is not None:
+            bound = "valu" if valu["busy"] > hbm_frac else "hbm"
+        else:
+            bound = "hbm (nominal; no current counters)"
         out = {
             "metric": "Mrays/s", "value": round(value, 2), "unit": "Mrays/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
@@ -276,15 +330,17 @@ def main():
                        "triangles": int(info.n_triangles), "bvh_nodes": int(info.n_nodes),
                        "rays_per_step_rank0": int(rays_step),
                        "primary_hit_fraction": round(hits / max(cnt.rays_primary, 1), 4), "camera_radii": CAMERA_RADII,
-                       "parallelism": ("tiles64-roundrobin+packed-gather-to-rank0" if tiles else
+                       "backend": (dist.get_backend() if world > 1 else None), "rccl_ranks": (dist.get_world_size() if world > 1 and dist.get_backend() == "nccl" else None),
+                       "parallelism": ("single-gpu" if world == 1 else "tiles64-roundrobin+hip-pack+one-gather-to-rank0+hip-unpack" if tiles else
                                        (f"sample-slices{world}+direct-reduce-scatter+gather-to-rank0" if samples else f"frames-dp{world}"))},
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"bound": bound, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                         "kernel": ("k_path_start+k_path_bounce (whole frame)" if spp else "k_stream<false, true>"),
-                         "kernel_ms": round(kernel_ms, 4),
+                         "achieved_is": "ALGORITHMIC bytes per launch / kernel time (SURVEY 8d); caches serve most of them, so it can exceed what HBM moves",
+                         "hbm_frac": hbm_frac, "valu": valu, "pmc": pmc,
+                         "kernel": kernel, "kernel_ms": round(kernel_ms, 4),
                          "algorithmic_bytes_per_launch": int(alg_bytes),
                          "node_visits": int(cnt.node_visits), "tri_tests": int(cnt.tri_tests),
-                         "bytes_per_ray": round(alg_bytes / max(rays_step, 1), 1), **pmc_extra},
+                         "bytes_per_ray": round(alg_bytes / max(rays_step, 1), 1)},
         }
         if not args.no_pipelined and not spp and world == 1:
             # Outside the contract's timed region and never `value`: the same frames with TWO in flight (a second context
@@ -310,6 +366,34 @@ def main():
                 ctx2.close()
             except Exception as ex:                                              # never fail the bench line for it
                 out["pipelined"] = {"error": str(ex)[:120]}
+        if not args.no_north_star and not spp and world == 1 and args.workload == "sphere_field_10k_1080p_primary_shadow":
+            # north_star's own target scene (1 M-triangle icosphere soup, 1080p, primary + shadow, ">= 1 Grays/s"): a
+            # driver-timed figure for it, measured after the timed region like `pipelined`; never `value`
+            try:
+                app_s, Ws, Hs = build_app(rt, "soup_1m_1080p_primary_shadow")
+                ctx_s = rt.Context(local_rank)
+                ctx_s.set_stream(stream.cuda_stream)
+                ctx_s.upload_scene(app_s.prepare_meshinfo())
+                ms_, ps_ = app_s.camera_view()
+                ctx_s.set_view(ms_, ps_, Ws, Hs)
+                ctx_s.render(flags=rt.FLAG_SHADOW | rt.FLAG_COUNTERS)
+                cs = ctx_s.counters()
+                rays_s = cs.rays_primary + cs.rays_shadow
+                for _ in range(5):
+                    ctx_s.render(flags=rt.FLAG_SHADOW)
+                ctx_s.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(args.steps):
+                    ctx_s.render(flags=rt.FLAG_SHADOW)
+                ctx_s.synchronize()
+                dts = time.perf_counter() - t0
+                out["north_star_scene"] = {"workload": "soup_1m_1080p_primary_shadow", "value": round(rays_s * args.steps / dts / 1e6, 2),
+                                           "unit": "Mrays/s", "ms_per_step": round(dts / args.steps * 1e3, 4), "steps": args.steps,
+                                           "rays_per_step": int(rays_s), "triangles": int(ctx_s.bvh_info().n_triangles),
+                                           "target": ">= 1000 Mrays/s primary+shadow at 1080p on a 1M-triangle scene (BASELINE.json north_star)"}
+                ctx_s.close(); app_s.close()
+            except Exception as ex:                                              # never fail the bench line for it
+                out["north_star_scene"] = {"error": str(ex)[:120]}
         if not args.no_cpu_baseline and not spp and world == 1:
             import oracle_py as orc
             view = orc.make_view(m, p, W, H)

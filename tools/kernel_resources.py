@@ -1,0 +1,96 @@
+#!/usr/bin/env python3
+"""Per-kernel resources of the gfx950 code object inside librt_amd.so: VGPRs, SGPRs, spills, private (scratch) bytes
+per lane, LDS -- read from the code object's own metadata (the AMDGPU msgpack note), not from a compiler log, so it
+describes the library that is actually loaded.
+
+    python tools/kernel_resources.py [path/to/librt_amd.so] [substring ...]
+
+Also the source of the stale-profile guard: `fingerprint(so, kernel)` = kernel symbol + its register / spill / scratch
+figures + a hash of the whole device ELF.  profiles/pmc_traffic.json records it when the PMC passes are summarised;
+bench.py quotes those counters only while the loaded library still has that fingerprint.
+"""
+import hashlib
+import os
+import struct
+import sys
+
+import msgpack
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DEFAULT_SO = os.path.join(ROOT, "ray-tracing_amd", "librt_amd.so")
+MAGIC = b"__CLANG_OFFLOAD_BUNDLE__"
+
+
+def device_elf(so_path=DEFAULT_SO, arch="gfx950"):
+    """The device ELF for `arch` out of the (uncompressed) clang offload bundle in the library's .hip_fatbin."""
+    blob = open(so_path, "rb").read()
+    base = blob.find(MAGIC)
+    if base < 0:
+        raise RuntimeError(f"{so_path}: no clang offload bundle (compressed bundles are not handled)")
+    (n,) = struct.unpack_from("<Q", blob, base + len(MAGIC))
+    off = base + len(MAGIC) + 8
+    for _ in range(n):
+        o, size, tlen = struct.unpack_from("<QQQ", blob, off)
+        off += 24
+        triple = blob[off:off + tlen].decode()
+        off += tlen
+        if arch in triple and size:
+            return blob[base + o: base + o + size]
+    raise RuntimeError(f"{so_path}: no {arch} code object in the bundle")
+
+
+def _notes(elf):
+    assert elf[:4] == b"\x7fELF" and elf[4] == 2, "not an ELF64"
+    shoff, = struct.unpack_from("<Q", elf, 0x28)
+    shentsize, shnum = struct.unpack_from("<HH", elf, 0x3A)
+    for i in range(shnum):
+        sh = shoff + i * shentsize
+        sh_type, = struct.unpack_from("<I", elf, sh + 4)
+        if sh_type != 7:        # SHT_NOTE
+            continue
+        o, size = struct.unpack_from("<QQ", elf, sh + 0x18)
+        p, end = o, o + size
+        while p + 12 <= end:
+            namesz, descsz, ntype = struct.unpack_from("<III", elf, p)
+            p += 12
+            name = elf[p:p + namesz].rstrip(b"\0")
+            p += (namesz + 3) & ~3
+            desc = elf[p:p + descsz]
+            p += (descsz + 3) & ~3
+            yield name, ntype, desc
+
+
+def kernel_table(so_path=DEFAULT_SO):
+    """{demangled-ish kernel symbol: dict(vgpr, sgpr, vgpr_spill, sgpr_spill, scratch_bytes, lds_bytes, max_flat_wg)}"""
+    elf = device_elf(so_path)
+    for name, ntype, desc in _notes(elf):
+        if name == b"AMDGPU" and ntype == 32:
+            md = msgpack.unpackb(desc, raw=False, strict_map_key=False)
+            out = {}
+            for k in md.get("amdhsa.kernels", []):
+                out[k[".name"]] = dict(vgpr=k.get(".vgpr_count"), agpr=k.get(".agpr_count", 0), sgpr=k.get(".sgpr_count"),
+                                       vgpr_spill=k.get(".vgpr_spill_count", 0), sgpr_spill=k.get(".sgpr_spill_count", 0),
+                                       scratch_bytes=k.get(".private_segment_fixed_size", 0),
+                                       lds_bytes=k.get(".group_segment_fixed_size", 0), max_flat_wg=k.get(".max_flat_workgroup_size"))
+            return out
+    raise RuntimeError("no AMDGPU metadata note in the device ELF")
+
+
+def fingerprint(so_path=DEFAULT_SO, kernel_substr="k_stream"):
+    """What a committed PMC summary is valid for: every kernel whose symbol contains kernel_substr with its resources,
+    and the hash of the device ELF."""
+    tab = kernel_table(so_path)
+    ks = {n: v for n, v in sorted(tab.items()) if kernel_substr in n}
+    return {"device_elf_sha16": hashlib.sha256(device_elf(so_path)).hexdigest()[:16], "kernels": ks}
+
+
+if __name__ == "__main__":
+    so = sys.argv[1] if len(sys.argv) > 1 and os.path.exists(sys.argv[1]) else DEFAULT_SO
+    pats = [a for a in sys.argv[1:] if a != so]
+    tab = kernel_table(so)
+    print(f"{so}: device ELF sha16 {hashlib.sha256(device_elf(so)).hexdigest()[:16]}")
+    print(f"{'kernel':70s} {'vgpr':>5s} {'sgpr':>5s} {'vspill':>6s} {'sspill':>6s} {'scratch':>8s} {'lds':>7s}")
+    for name, r in sorted(tab.items()):
+        if pats and not any(p in name for p in pats):
+            continue
+        print(f"{name[:70]:70s} {r['vgpr']:5d} {r['sgpr']:5d} {r['vgpr_spill']:6d} {r['sgpr_spill']:6d} {r['scratch_bytes']:8d} {r['lds_bytes']:7d}")

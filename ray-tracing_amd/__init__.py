@@ -102,6 +102,14 @@ def lib():
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(f"{LIB_PATH} is missing: run `make -C ray-tracing_amd` (or __graft_entry__.build()). "
                            "ray_tracing_amd has no CPU fallback.")
+    # One HIP runtime per process: librt_amd.so asks for "libamdhip64.so", the name PyTorch-ROCm loads its bundled runtime
+    # under, so with torch in the process first both share that runtime (torch streams and tensors can be handed to the
+    # library); loaded the other way round, torch would bring a second runtime that may find no GPU.  So torch goes first
+    # wherever it exists (tests, bench); without torch the library takes /opt/rocm/lib's runtime.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(LIB_PATH)
     vp, u32, u64, sz, fp, i = C.c_void_p, C.c_uint32, C.c_uint64, C.c_size_t, C.POINTER(C.c_float), C.c_int
     sig = {

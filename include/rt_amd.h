@@ -145,6 +145,30 @@ typedef struct {
 int rt_render(rt_ctx *ctx, const rt_render_params *params);
 int rt_synchronize(rt_ctx *ctx);
 
+/* ---- the same frame, allocating nothing ------------------------------------------------------------------------
+ * No counterpart in the reference (its node creates new GPU buffers every frame, src/node.rs:42-50).  For callers
+ * that cannot allocate: code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc.
+ * rt_render_static renders what rt_render(params) would -- same kernels, same bits -- but
+ *   - writes into the CALLER's device buffers: d_radiance (n_pixels * 4 f32), d_prim_ids (n_pixels u32), d_hit_t
+ *     (n_pixels f32), all required; d_accum (n_pixels * 4 f32, the running sums) required with RT_FLAG_PATH_TRACE.
+ *     n_pixels must be width * height of the current rt_set_view.  Pixels the call does not cover (viewport, other
+ *     ranks' tiles) are cleared on every call.  Without RT_FLAG_ACCUMULATE d_accum restarts from zero; the number of
+ *     samples it holds is kept in the context.
+ *   - keeps the frame's scratch (work-queue heads, counters, path queues, contribution plane) in a static device
+ *     array of RT_STATIC_SCRATCH_BYTES = 32 MiB that every GPU the library runs on holds until the process ends.
+ *     Primary / shadow frames use 1.2 KB of it at any frame size; path tracing uses 104 B per pixel (one sample per
+ *     launch), so frames beyond RT_STATIC_MAX_PATH_PIXELS (322,560; 640x360 fits) return RT_ERR_ARG with a message
+ *     that says so.  RT_FLAG_TIME_KERNELS is refused (it creates events).
+ *   - calls no hipMalloc / hipFree / hipEventCreate or any other allocating routine, first call included (scene and
+ *     view are set up beforehand with rt_upload_scene / rt_set_view, which do allocate).
+ * Asynchronous on the context's stream; rt_get_counters then reports this frame.  ALL calls on one GPU share that GPU's
+ * array: calls that overlap on one GPU (two contexts, two streams) race -- serialise them.  The array keeps the last
+ * call's contents; what must start at zero is cleared by the call itself. */
+#define RT_STATIC_SCRATCH_BYTES   (32u << 20)
+#define RT_STATIC_MAX_PATH_PIXELS 322560u
+int rt_render_static(rt_ctx *ctx, const rt_render_params *params, void *d_radiance, void *d_prim_ids, void *d_hit_t,
+                     void *d_accum, size_t n_pixels);
+
 /* ---- results: replace the colour-attachment write (src/node.rs:63-69) -----------------
  * Caller-allocated host buffers; each call synchronises the stream first.
  * radiance: W*H*4 f32 linear unclamped RGBA (path tracing: accumulated sum / samples).

@@ -80,7 +80,7 @@ class EntityView(C.Structure):
 RT_SYMBOLS = ["rt_create", "rt_destroy", "rt_set_stream", "rt_upload_scene", "rt_upload_scene_ex", "rt_update_vertices", "rt_update_vertex_range", "rt_host_bvh_refit", "rt_set_view", "rt_render",
               "rt_synchronize", "rt_read_radiance", "rt_read_prim_ids", "rt_read_hit_t", "rt_read_bgra8_srgb",
               "rt_read_accumulation", "rt_device_buffers", "rt_resolve_accumulation", "rt_get_counters",
-              "rt_encode_bgra8_srgb", "rt_tile_slot_bytes", "rt_pack_tiles", "rt_unpack_tiles",
+              "rt_encode_bgra8_srgb", "rt_tile_slot_bytes", "rt_pack_tiles", "rt_unpack_tiles", "rt_render_static",
               "rt_get_bvh_info", "rt_read_bvh", "rt_read_bvh_wide", "rt_host_bvh_build", "rt_host_bvh_copy", "rt_host_bvh_wide", "rt_host_bvh_free", "rt_last_error", "rt_status_string", "rt_version"]
 RTH_SYMBOLS = ["rth_app_create", "rth_app_destroy", "rth_app_finish", "rth_app_update", "rth_app_ctx",
                "rth_last_error", "rth_add_mesh", "rth_add_cuboid", "rth_add_plane", "rth_add_icosphere",

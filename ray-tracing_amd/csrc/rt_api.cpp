@@ -942,6 +942,7 @@ constexpr size_t kStaticCntBytes = 4096;                                   // RT
 constexpr size_t kStaticPathBytesPerPx = 2 * 11 * 4 + 16;                  // two queues of 11 dwords + one float4 plane
 constexpr size_t kStaticAlignSlack = 16 * 256;                             // every sub-buffer starts on a 256-B boundary
 constexpr size_t kStaticMaxPathPx = (RT_STATIC_SCRATCH_BYTES - kStaticCntBytes - kStaticAlignSlack) / kStaticPathBytesPerPx;
+static_assert(kStaticMaxPathPx == RT_STATIC_MAX_PATH_PIXELS, "include/rt_amd.h documents this limit");
 }  // namespace
 int rt_render_static(rt_ctx *c, const rt_render_params *params, void *d_radiance, void *d_prim_ids, void *d_hit_t,
                      void *d_accum, size_t n_pixels) {

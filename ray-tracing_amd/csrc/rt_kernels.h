@@ -73,7 +73,9 @@ hipError_t rtk_launch_tile_unpack(hipStream_t st, float *frame, const float *pac
                                   uint32_t tile, uint32_t tiles_x, uint32_t n_tiles, uint32_t count, uint32_t first_rank, uint32_t n_src);
 
 // rt_render_static: the address, on the CURRENT device, of the file-scope scratch array (RT_STATIC_SCRATCH_BYTES)
-#define RT_STATIC_SCRATCH_BYTES (32u << 20)
+#ifndef RT_STATIC_SCRATCH_BYTES
+#define RT_STATIC_SCRATCH_BYTES (32u << 20)      // include/rt_amd.h has the same value (static_asserted in rt_api.cpp)
+#endif
 hipError_t rtk_static_scratch_address(void **ptr);
 
 hipError_t rtk_launch_fill_u32(hipStream_t st, uint32_t *p, uint32_t value, size_t n);

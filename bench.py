@@ -156,8 +156,12 @@ def main():
     if "BENCH_FORCE_DEVICE" in os.environ:
         local_rank = int(os.environ["BENCH_FORCE_DEVICE"])
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    # BENCH_FORCE_DIST=1 (rehearsal hook): a ONE-rank process group, so that the RCCL code path of the collective modes
+    # (device tensors, pack -> gather -> unpack on one stream) can run on a one-GPU box.  Never set by the driver.
+    force_dist = world == 1 and bool(os.environ.get("BENCH_FORCE_DIST"))
+    if world > 1 or force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         backend = os.environ.get("BENCH_BACKEND", "nccl")
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
@@ -167,8 +171,9 @@ def main():
     import ray_tracing_amd as rt
 
     app, W, H = build_app(rt, args.workload, rank, world)
-    tiles = args.mode == "tiles" and world > 1
-    samples = args.mode == "samples" and world > 1
+    distributed = world > 1 or force_dist
+    tiles = args.mode == "tiles" and distributed
+    samples = args.mode == "samples" and distributed
     if samples and len(WORKLOADS[args.workload]) <= 5:
         raise SystemExit("--mode samples needs a path-tracing workload")
     if world > 1 and not tiles and not samples:
@@ -248,14 +253,14 @@ def main():
     for _ in range(args.warmup):
         step(flags)
     torch.cuda.synchronize()
-    if world > 1:
+    if distributed:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step(flags | rt.FLAG_TIME_KERNELS)
     torch.cuda.synchronize()
-    if world > 1:
+    if distributed:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
@@ -263,7 +268,7 @@ def main():
     kernel_ms = kc.kernel_ms / (args.steps if spp else max(kc.kernel_launches, 1))   # per launch; per frame when path tracing
 
     total_rays = float(rays_step)
-    if world > 1:
+    if distributed:
         tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
@@ -330,8 +335,8 @@ def main():
                        "triangles": int(info.n_triangles), "bvh_nodes": int(info.n_nodes),
                        "rays_per_step_rank0": int(rays_step),
                        "primary_hit_fraction": round(hits / max(cnt.rays_primary, 1), 4), "camera_radii": CAMERA_RADII,
-                       "backend": (dist.get_backend() if world > 1 else None), "rccl_ranks": (dist.get_world_size() if world > 1 and dist.get_backend() == "nccl" else None),
-                       "parallelism": ("single-gpu" if world == 1 else "tiles64-roundrobin+hip-pack+one-gather-to-rank0+hip-unpack" if tiles else
+                       "backend": (dist.get_backend() if distributed else None), "rccl_ranks": (dist.get_world_size() if distributed and dist.get_backend() == "nccl" else None),
+                       "parallelism": ("single-gpu" if not distributed else ("tiles64-roundrobin+host-pack+gather-to-rank0 (gloo rehearsal)" if gloo else "tiles64-roundrobin+hip-pack+one-gather-to-rank0+hip-unpack") if tiles else
                                        (f"sample-slices{world}+direct-reduce-scatter+gather-to-rank0" if samples else f"frames-dp{world}"))},
             "roofline": {"bound": bound, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
@@ -473,7 +478,7 @@ def main():
             out["roofline"]["stream_copy_error"] = str(ex)[:80]
         print(json.dumps(out), flush=True)
     ctx.close()
-    if world > 1:
+    if distributed:
         dist.barrier()                 # rank 0's CPU baseline is done before anyone tears the group down
         dist.destroy_process_group()
 

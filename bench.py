@@ -348,27 +348,29 @@ def main():
                          "bytes_per_ray": round(alg_bytes / max(rays_step, 1), 1)},
         }
         if not args.no_pipelined and not spp and world == 1:
-            # Outside the contract's timed region and never `value`: the same frames with TWO in flight (a second context
-            # = second stream + second set of frame buffers, alternate frames).  The waves of one frame fill the chip while
-            # the other frame's last regions drain ("the end of the frame").
+            # Outside the contract's timed region and never `value`: the same frames with TWO in flight inside this one
+            # context (rt_set_frames_in_flight: a second set of frame buffers and a second stream, taken in turn).  The waves
+            # of one frame fill the chip while the other frame's last regions drain ("the end of the frame").
             try:
-                ctx2 = rt.Context(local_rank)
-                ctx2.upload_scene(scene)
-                ctx2.set_view(m, p, W, H)
-                for _ in range(3):
-                    ctx.render(flags=flags); ctx2.render(flags=flags)
-                ctx.synchronize(); ctx2.synchronize()
+                ctx.set_stream(0)                      # the context's own streams: one per frame set
+                ctx.set_frames_in_flight(2)
+                for _ in range(4):
+                    ctx.render(flags=flags)
+                ctx.synchronize()
                 n2 = max(2, args.steps - args.steps % 2)
                 t0 = time.perf_counter()
-                for _ in range(n2 // 2):
-                    ctx.render(flags=flags); ctx2.render(flags=flags)
-                ctx.synchronize(); ctx2.synchronize()
+                for _ in range(n2):
+                    ctx.render(flags=flags)
+                ctx.synchronize()
                 dt2 = time.perf_counter() - t0
-                same = bool((ctx.read_prim_ids() == ctx2.read_prim_ids()).all())
+                prim_b = ctx.read_prim_ids()
+                ctx.set_frames_in_flight(1)
+                ctx.render(flags=flags)
+                same = bool((ctx.read_prim_ids() == prim_b).all())
+                ctx.set_stream(stream.cuda_stream)
                 out["pipelined"] = {"frames_in_flight": 2, "value": round(rays_step * n2 / dt2 / 1e6, 2), "unit": "Mrays/s",
                                     "ms_per_step": round(dt2 / n2 * 1e3, 4), "steps": n2, "frames_identical": same,
-                                    "note": "two contexts on one GPU rendering alternate frames; not the contract's value"}
-                ctx2.close()
+                                    "note": "ONE context, rt_set_frames_in_flight(2): two sets of frame buffers and streams taken in turn by rt_render; not the contract's value"}
             except Exception as ex:                                              # never fail the bench line for it
                 out["pipelined"] = {"error": str(ex)[:120]}
         if not args.no_north_star and not spp and world == 1 and args.workload == "sphere_field_10k_1080p_primary_shadow":

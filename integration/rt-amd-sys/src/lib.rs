@@ -89,6 +89,8 @@ extern "C" {
     pub fn rt_create(device_ordinal: c_int, out: *mut *mut rt_ctx) -> c_int;
     pub fn rt_destroy(ctx: *mut rt_ctx) -> c_int;
     pub fn rt_set_stream(ctx: *mut rt_ctx, hip_stream: *mut c_void) -> c_int;
+    /// 1..4 frames in flight inside one context (sets of frame buffers + streams taken in turn by rt_render).
+    pub fn rt_set_frames_in_flight(ctx: *mut rt_ctx, n: u32) -> c_int;
     pub fn rt_upload_scene(ctx: *mut rt_ctx,
         triangles: *const rt_triangle, n_triangles: usize, meshes: *const rt_mesh_info, n_meshes: usize,
         vertices: *const rt_vertex, n_vertices: usize, materials: *const rt_material, n_materials: usize) -> c_int;

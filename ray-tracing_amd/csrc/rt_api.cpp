@@ -26,9 +26,26 @@ struct QueueMem {
 };
 }  // namespace
 
+// Frames in flight (rt_set_frames_in_flight): every set is one frame's outputs, its counters / work-queue heads and the
+// stream it is rendered on.  rt_render takes the sets in turn; the context's d_rgba / d_prim / d_t / d_cnt / h_cnt / stream
+// members are ALIASES of the set rendered last, so every reader sees the latest frame.
+#define RT_MAX_IN_FLIGHT 4
+struct FrameSet {
+    float *d_rgba = nullptr, *d_t = nullptr;
+    uint32_t *d_prim = nullptr;
+    unsigned long long *d_cnt = nullptr, *h_cnt = nullptr;
+    hipStream_t own_stream = nullptr;
+    uint32_t coverage[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // what the buffers were last cleared for, compared field by field
+    bool coverage_valid = false;
+};
+
 struct rt_ctx {
     int device = 0;
     hipStream_t own_stream = nullptr, stream = nullptr;
+    hipStream_t ext_stream = nullptr;     // rt_set_stream: every set runs on the caller's stream (frames then serialise)
+    bool use_null_stream = false;
+    FrameSet fs[RT_MAX_IN_FLIGHT];
+    uint32_t n_sets = 1, cur_set = 0;
     std::string err;
 
     // scene
@@ -60,11 +77,9 @@ struct rt_ctx {
     float *d_rgba = nullptr, *d_accum = nullptr, *d_t = nullptr;
     uint32_t *d_prim = nullptr;
     uint8_t *d_bgra = nullptr;
-    // what the buffers were last cleared for: (rank, count, tile, vx, vy, vw, vh, partial), compared field by field
-    uint32_t coverage[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    bool coverage_valid = false;
     hipEvent_t ev_update[2] = {nullptr, nullptr};   // timing of rt_update_vertices / rt_update_vertex_range (created once)
     uint32_t accum_samples = 0;
+    uint32_t accum_cov[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // the coverage the running sums were started under
     bool accum_dirty = false;        // camera moved: the next path-traced frame restarts accumulation
 
     // path queues (2, ping-pong) and the per-sample contribution planes of a batch of samples
@@ -109,6 +124,28 @@ int fail(rt_ctx *c, int code, const char *what, hipError_t e = hipSuccess) {
 
 void free_dev(void *&p) { if (p) { (void)hipFree(p); p = nullptr; } }
 
+hipStream_t set_stream_of(const rt_ctx *c, uint32_t k) {
+    if (c->use_null_stream) return nullptr;
+    return c->ext_stream ? c->ext_stream : c->fs[k].own_stream;
+}
+// the context's aliases point at set k
+void select_set(rt_ctx *c, uint32_t k) {
+    c->cur_set = k;
+    c->d_rgba = c->fs[k].d_rgba; c->d_t = c->fs[k].d_t; c->d_prim = c->fs[k].d_prim;
+    c->d_cnt = c->fs[k].d_cnt; c->h_cnt = c->fs[k].h_cnt;
+    c->stream = set_stream_of(c, k);
+}
+// every stream any frame of this context may still be running on
+hipError_t sync_all(rt_ctx *c) {
+    hipError_t first = hipSuccess;
+    for (uint32_t k = 0; k < c->n_sets; ++k) {
+        hipError_t e = hipStreamSynchronize(set_stream_of(c, k));
+        if (e != hipSuccess && first == hipSuccess) first = e;
+    }
+    return first;
+}
+void invalidate_coverage(rt_ctx *c) { for (FrameSet &f : c->fs) f.coverage_valid = false; }
+
 void free_scene(rt_ctx *c) {
     free_dev(c->d_nodes); free_dev(c->d_recs); free_dev(c->d_tris);
     free_dev(c->d_meshes); free_dev(c->d_verts); free_dev(c->d_mats);
@@ -122,10 +159,14 @@ void free_scene(rt_ctx *c) {
 
 void free_frame(rt_ctx *c) {
     void *p;
-    p = c->d_rgba; free_dev(p); c->d_rgba = nullptr;
+    for (FrameSet &f : c->fs) {
+        p = f.d_rgba; free_dev(p); f.d_rgba = nullptr;
+        p = f.d_t; free_dev(p); f.d_t = nullptr;
+        p = f.d_prim; free_dev(p); f.d_prim = nullptr;
+        f.coverage_valid = false;
+    }
+    c->d_rgba = nullptr; c->d_t = nullptr; c->d_prim = nullptr;
     p = c->d_accum; free_dev(p); c->d_accum = nullptr;
-    p = c->d_t; free_dev(p); c->d_t = nullptr;
-    p = c->d_prim; free_dev(p); c->d_prim = nullptr;
     p = c->d_bgra; free_dev(p); c->d_bgra = nullptr;
     for (int i = 0; i < 2; ++i) {
         p = c->q[i].f; free_dev(p); c->q[i].f = nullptr;
@@ -237,17 +278,21 @@ int rt_create(int device_ordinal, rt_ctx **out) {
         c->tune.uni_min = env("RT_TUNE_UNI_MIN", 16, 1, 65);
         c->tune.wide_vote_node = env("RT_TUNE_WIDE_VOTE_NODE", 3, 1, 64);
         c->tune.wide_vote_tri = env("RT_TUNE_WIDE_VOTE_TRI", 1, 1, 64);
+        c->tune.pool_dep = env("RT_TUNE_POOL_DEP", 0, 0, 32);
+        c->tune.pool_pick = env("RT_TUNE_POOL_PICK", 40, 1, 64);
+        c->tune.pool_drain = env("RT_TUNE_POOL_DRAIN", 0, 0, 1);
         c->tune_wide = env("RT_TUNE_WIDE", 1, 0, 1);
         c->tune_sample_batch = env("RT_TUNE_SAMPLE_BATCH", 16, 1, 16);
     }
     int rc = RT_OK;
     do {
         if ((e = hipSetDevice(device_ordinal)) != hipSuccess) { rc = fail(nullptr, RT_ERR_HIP, "hipSetDevice", e); break; }
-        if ((e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking)) != hipSuccess) { rc = fail(nullptr, RT_ERR_HIP, "hipStreamCreate", e); break; }
-        c->stream = c->own_stream;
-        if ((e = hipMalloc((void **)&c->d_cnt, RT_CNT_N * sizeof(unsigned long long))) != hipSuccess) { rc = fail(nullptr, RT_ERR_HIP, "hipMalloc counters", e); break; }
-        if ((e = hipHostMalloc((void **)&c->h_cnt, RT_CNT_N * sizeof(unsigned long long), hipHostMallocDefault)) != hipSuccess) { rc = fail(nullptr, RT_ERR_HIP, "hipHostMalloc counters", e); break; }
-        std::memset(c->h_cnt, 0, RT_CNT_N * sizeof(unsigned long long));
+        if ((e = hipStreamCreateWithFlags(&c->fs[0].own_stream, hipStreamNonBlocking)) != hipSuccess) { rc = fail(nullptr, RT_ERR_HIP, "hipStreamCreate", e); break; }
+        c->own_stream = c->fs[0].own_stream;
+        if ((e = hipMalloc((void **)&c->fs[0].d_cnt, RT_CNT_N * sizeof(unsigned long long))) != hipSuccess) { rc = fail(nullptr, RT_ERR_HIP, "hipMalloc counters", e); break; }
+        if ((e = hipHostMalloc((void **)&c->fs[0].h_cnt, RT_CNT_N * sizeof(unsigned long long), hipHostMallocDefault)) != hipSuccess) { rc = fail(nullptr, RT_ERR_HIP, "hipHostMalloc counters", e); break; }
+        std::memset(c->fs[0].h_cnt, 0, RT_CNT_N * sizeof(unsigned long long));
+        select_set(c, 0);
         // the static scratch array of rt_render_static: every device holds its own copy at its own address, so the
         // address is asked for here, once per context, with this context's device current
         if ((e = rtk_static_scratch_address(&c->static_scratch)) != hipSuccess) { rc = fail(nullptr, RT_ERR_HIP, "hipGetSymbolAddress(rt_static_scratch)", e); break; }
@@ -260,14 +305,16 @@ int rt_create(int device_ordinal, rt_ctx **out) {
 int rt_destroy(rt_ctx *c) {
     if (!c) return RT_OK;
     (void)hipSetDevice(c->device);
-    (void)hipStreamSynchronize(c->stream);
+    (void)sync_all(c);
     free_scene(c);
     free_frame(c);
-    if (c->d_cnt) (void)hipFree(c->d_cnt);
-    if (c->h_cnt) (void)hipHostFree(c->h_cnt);
+    for (FrameSet &f : c->fs) {
+        if (f.d_cnt) (void)hipFree(f.d_cnt);
+        if (f.h_cnt) (void)hipHostFree(f.h_cnt);
+    }
     for (hipEvent_t ev : c->ev) (void)hipEventDestroy(ev);
     for (hipEvent_t ev : c->ev_update) if (ev) (void)hipEventDestroy(ev);
-    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    for (FrameSet &f : c->fs) if (f.own_stream) (void)hipStreamDestroy(f.own_stream);
     delete c;
     return RT_OK;
 }
@@ -275,16 +322,42 @@ int rt_destroy(rt_ctx *c) {
 int rt_set_stream(rt_ctx *c, void *hip_stream) {
     if (!c) return RT_ERR_ARG;
     (void)hipSetDevice(c->device);
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    if (hip_stream == RT_STREAM_NULL) c->stream = nullptr;          // HIP's null stream, asked for explicitly
-    else c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+    HIPCHK(c, sync_all(c));
+    c->use_null_stream = hip_stream == RT_STREAM_NULL;          // HIP's null stream, asked for explicitly
+    c->ext_stream = c->use_null_stream ? nullptr : (hipStream_t)hip_stream;   // NULL: back on the sets' own streams
+    select_set(c, c->cur_set);
+    return RT_OK;
+}
+
+int rt_set_frames_in_flight(rt_ctx *c, uint32_t n) {
+    if (!c) return RT_ERR_ARG;
+    if (n == 0 || n > RT_MAX_IN_FLIGHT) return fail(c, RT_ERR_ARG, "rt_set_frames_in_flight: 1..4 frames");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, sync_all(c));
+    for (uint32_t k = 1; k < n; ++k) {      // sets beyond the first get their stream, counters and (if a view exists) frame buffers
+        FrameSet &f = c->fs[k];
+        if (!f.own_stream) HIPCHK(c, hipStreamCreateWithFlags(&f.own_stream, hipStreamNonBlocking));
+        if (!f.d_cnt) HIPCHK(c, hipMalloc((void **)&f.d_cnt, RT_CNT_N * sizeof(unsigned long long)));
+        if (!f.h_cnt) {
+            HIPCHK(c, hipHostMalloc((void **)&f.h_cnt, RT_CNT_N * sizeof(unsigned long long), hipHostMallocDefault));
+            std::memset(f.h_cnt, 0, RT_CNT_N * sizeof(unsigned long long));
+        }
+        if (c->n_px && !f.d_rgba) {
+            HIPCHK(c, hipMalloc((void **)&f.d_rgba, c->n_px * 16));
+            HIPCHK(c, hipMalloc((void **)&f.d_t, c->n_px * 4));
+            HIPCHK(c, hipMalloc((void **)&f.d_prim, c->n_px * 4));
+            f.coverage_valid = false;
+        }
+    }
+    c->n_sets = n;
+    if (c->cur_set >= n) select_set(c, 0);
     return RT_OK;
 }
 
 int rt_synchronize(rt_ctx *c) {
     if (!c) return RT_ERR_ARG;
     HIPCHK(c, hipSetDevice(c->device));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, sync_all(c));
     return RT_OK;
 }
 
@@ -402,7 +475,7 @@ int rt_upload_scene_ex(rt_ctx *c, const rt_triangle *tris, size_t n_tris, const 
     }
 
     HIPCHK(c, hipSetDevice(c->device));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, sync_all(c));
     free_scene(c);
 
     RtBvhBuildResult bvh;
@@ -534,7 +607,7 @@ int rt_upload_scene_ex(rt_ctx *c, const rt_triangle *tris, size_t n_tris, const 
     c->bvh_host_stale = false;
     c->has_scene = true;
     c->accum_samples = 0;
-    c->coverage_valid = false;
+    invalidate_coverage(c);
     return RT_OK;
 }
 
@@ -550,6 +623,7 @@ int rt_update_vertices(rt_ctx *c, const rt_vertex *verts, size_t n_verts, const 
     if (c->bvh_host.dropped)   // triangles left out of the tree at build time could have become valid
         return fail(c, RT_ERR_SCENE, "rt_update_vertices: the built tree dropped non-finite triangles, rebuild with rt_upload_scene");
     HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, sync_all(c));          // frames in flight on other sets still walk the tree this call rewrites
     double refit_ms = 0.0;
     if (std::getenv("RT_TUNE_HOST_REFIT")) {
         // the round's first version, kept for A/B and as the reference the GPU refit is tested against: refit on
@@ -646,6 +720,7 @@ int rt_update_vertex_range(rt_ctx *c, const rt_vertex *verts, size_t first_verte
             amax = std::fmax(amax, std::fabs(verts[i].pos[k]));
         }
     HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, sync_all(c));          // frames in flight on other sets still walk the tree this call rewrites
     const size_t nn = c->S.n_nodes;
     // Which nodes have a moved mesh below them: walked on the host's copy of the topology (mesh-id spans per node), a few
     // thousand nodes for a mesh of a few hundred triangles.  A short list is redone by ONE launch (k_refit_list); a long
@@ -746,17 +821,20 @@ int rt_set_view(rt_ctx *c, const float m[16], const float pos[3], uint32_t width
     HIPCHK(c, hipSetDevice(c->device));
     size_t n_px = (size_t)width * height;
     if (n_px != c->n_px || c->V.width != width) {
-        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, sync_all(c));
         // until every buffer of the new size exists there is no view: a failed allocation leaves rt_render at
         // RT_NOT_READY instead of launching on freed or NULL buffers
         const bool had_view = c->has_view;
         c->has_view = false;
-        c->coverage_valid = false;
+        invalidate_coverage(c);
         free_frame(c);
-        HIPCHK(c, hipMalloc((void **)&c->d_rgba, n_px * 16));
+        for (uint32_t k = 0; k < c->n_sets; ++k) {
+            HIPCHK(c, hipMalloc((void **)&c->fs[k].d_rgba, n_px * 16));
+            HIPCHK(c, hipMalloc((void **)&c->fs[k].d_t, n_px * 4));
+            HIPCHK(c, hipMalloc((void **)&c->fs[k].d_prim, n_px * 4));
+        }
         HIPCHK(c, hipMalloc((void **)&c->d_accum, n_px * 16));
-        HIPCHK(c, hipMalloc((void **)&c->d_t, n_px * 4));
-        HIPCHK(c, hipMalloc((void **)&c->d_prim, n_px * 4));
+        select_set(c, c->cur_set);
         c->n_px = n_px;
         c->accum_samples = 0;
         c->has_view = had_view;
@@ -879,18 +957,25 @@ int rt_render(rt_ctx *c, const rt_render_params *params) {
     if (rc != RT_OK) return rc;
     HIPCHK(c, hipSetDevice(c->device));
 
+    // Frames in flight: primary / shadow frames take the sets in turn (each set has its own stream, so frame k + 1 fills
+    // the compute units frame k's last regions leave idle); path-traced frames share ONE accumulation buffer and the path
+    // queues, so they all run on set 0, after everything else in flight.
+    const bool path_frame = (P.flags & RT_FLAG_PATH_TRACE) != 0;
+    if (c->n_sets > 1) {
+        if (path_frame) { HIPCHK(c, sync_all(c)); select_set(c, 0); }
+        else select_set(c, (c->cur_set + 1) % c->n_sets);
+    }
+    FrameSet &F = c->fs[c->cur_set];
     RenderTargets T{};
     T.rgba = c->d_rgba; T.accum = c->d_accum; T.t = c->d_t; T.prim = c->d_prim; T.cnt = c->d_cnt;
     // Pixels this call does not cover (outside the viewport, other ranks' tiles) must read as cleared; clear only
     // when the coverage changes.
     const uint32_t cov[8] = {sh.rank, sh.count, sh.tile, c->V.vx, c->V.vy, c->V.vw, c->V.vh, partial ? 1u : 0u};
-    if (!c->coverage_valid || std::memcmp(cov, c->coverage, sizeof cov) != 0) {
+    if (!F.coverage_valid || std::memcmp(cov, F.coverage, sizeof cov) != 0) {
         rc = clear_outputs(c, T);
         if (rc != RT_OK) return rc;
-        std::memcpy(c->coverage, cov, sizeof cov);
-        c->coverage_valid = true;
-        c->accum_samples = 0;   // coverage changed: accumulation restarts (intent of src/scene.rs:94-96)
-        HIPCHK(c, hipMemsetAsync(c->d_accum, 0, c->n_px * 16, c->stream));
+        std::memcpy(F.coverage, cov, sizeof cov);
+        F.coverage_valid = true;
     }
     if (P.flags & RT_FLAG_PATH_TRACE) {
         T.max_batch = c->tune_sample_batch;
@@ -902,10 +987,13 @@ int rt_render(rt_ctx *c, const rt_render_params *params) {
         T.max_batch = std::min(c->tune_sample_batch, c->contrib_planes);
         T.qa = queue_view(c->q[0], c->q_capacity); T.qb = queue_view(c->q[1], c->q_capacity);
         T.contrib = c->d_contrib;
-        if (!(P.flags & RT_FLAG_ACCUMULATE) || c->accum_dirty) {
+        // the running sums restart unless asked to go on -- and also when the camera or the geometry moved or the coverage
+        // is not the one they were started under (intent of src/scene.rs:94-96)
+        if (!(P.flags & RT_FLAG_ACCUMULATE) || c->accum_dirty || std::memcmp(cov, c->accum_cov, sizeof cov) != 0) {
             HIPCHK(c, hipMemsetAsync(c->d_accum, 0, c->n_px * 16, c->stream));
             c->accum_samples = 0;
             c->accum_dirty = false;
+            std::memcpy(c->accum_cov, cov, sizeof cov);
         }
     }
 

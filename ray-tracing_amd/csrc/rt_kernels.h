@@ -23,6 +23,7 @@ struct RtTune {
     uint32_t vote_node, vote_tri;   // relative issue cost of a node step / a triangle step (phase vote)
     uint32_t uni_min;          // lanes that must share one node for the scalar node fetch (65 = never)
     uint32_t wide_vote_node, wide_vote_tri;   // the same vote weights when the 4-wide tree is walked
+    uint32_t pool_dep, pool_pick, pool_drain;   // k_stream's tail pool: deposit at <= pool_dep unfinished rays (0 = off), pick up at >= pool_pick pooled rays
 };
 hipError_t rtk_launch_primary(hipStream_t st, const RtSceneDev &S, const RtViewDev &V, const RtShardDev &sh,
                               uint32_t flags, float *rgba, uint32_t *prim, float *t,

@@ -652,17 +652,47 @@ __device__ __forceinline__ bool pixel_of_region(const RtViewDev &V, const RtShar
     return xx < V.vw && yy < V.vh;
 }
 
-template <bool COUNT, bool WIDE>
+// ---- the block's tail pool (round 2) ------------------------------------------------------------------------------
+// A wave lives as long as its longest ray: 42 % of the lane slots of a node trip belonged to rays that had already
+// ended, and about half of a wave's trips ran with <= 16 of its 64 rays unfinished.  Refilling the freed lanes with
+// fresh rays was measured again and again to lose more than it gains (fresh rays walk the top of the tree while the
+// stragglers are deep in it: no shared fetches, split votes).  The pool re-packs rays of the SAME kind instead: a wave
+// that is down to its last <= pool_dep rays DEPOSITS them -- ray, closest hit so far, current node and the stack -- in a
+// small LDS pool of its block and takes a fresh 8x8 region with all 64 lanes; a wave that is out of work takes
+// up to 64 pooled rays at once (stragglers of the block's four waves, i.e. of neighbouring regions) and walks them
+// as one full wave.  Fresh waves stay all-fresh, straggler waves are all stragglers, and the stragglers run with
+// several times the lane occupancy.  A ray's own sequence of steps does not change (only which lane executes them), so
+// results and counted visits are identical.
+// Protocol (all in LDS, one lock per block): deposits and pick-ups copy under the lock; s_running counts the block's
+// waves that have not left yet; a wave deposits only while another wave is still there to pick up (s_running >= 2) and
+// leaves only after looking at the pool under the lock -- the last wave of a block (s_running == 1) takes what is
+// there, so no ray is ever left behind and every wave reaches its exit.
+#ifndef RT_POOL
+#define RT_POOL 64           // pooled rays per block
+#endif
+struct RtStreamTune {
+    uint32_t refill_min, finish_min, vote_node, vote_tri, uni_min;
+    uint32_t pool_dep;       // a wave with <= this many unfinished rays deposits them (0: the pool is off)
+    uint32_t pool_pick;      // an idle wave takes pooled rays before a fresh region once this many wait
+    uint32_t pool_drain;     // deposits also once the work queues are empty (the frame's end): 0 / 1
+};
+
+template <bool COUNT, bool WIDE, bool POOL>
 __device__ __forceinline__ void stream_body(
-    const RtSceneDev &S_, const RtViewDev &V_, const RtShardDev &sh_, uint32_t flags, uint32_t refill_min, uint32_t finish_min,
-    uint32_t vote_node, uint32_t vote_tri, uint32_t uni_min, float4 *__restrict__ rgba, uint32_t *__restrict__ prim,
-    float *__restrict__ tout, unsigned long long *__restrict__ counters) {
+    const RtSceneDev &S_, const RtViewDev &V_, const RtShardDev &sh_, uint32_t flags, const RtStreamTune tn,
+    float4 *__restrict__ rgba, uint32_t *__restrict__ prim, float *__restrict__ tout, unsigned long long *__restrict__ counters) {
     __shared__ int s_stack[RT_STACK_LDS * RT_BLOCK];
     // what only the hand-over code reads lives in LDS, not in ~60 SGPRs that the hot loop would spill
     __shared__ RtSceneDev S;
     __shared__ RtViewDev V;
     __shared__ RtShardDev sh;
-    if (threadIdx.x == 0) { S = S_; V = V_; sh = sh_; }
+    // the tail pool: SoA, slot-major inside a plane (consecutive lanes -> consecutive banks)
+    constexpr uint32_t NP = POOL ? RT_POOL : 1;     // the kernel built without the pool keeps no LDS for it
+    __shared__ float s_pool_f[9][NP];               // o.xyz d.xyz t hu hv
+    __shared__ uint32_t s_pool_u[6][NP];            // seq rec cur sp idx state
+    __shared__ int s_pool_stk[RT_STACK_LDS][NP];
+    __shared__ uint32_t s_pool_n, s_pool_lock, s_running;
+    if (threadIdx.x == 0) { S = S_; V = V_; sh = sh_; s_pool_n = 0u; s_pool_lock = 0u; s_running = RT_BLOCK / 64u; }
     __syncthreads();
     lds_int *stk = (lds_int *)(s_stack + threadIdx.x);
     int ovf_mem[RT_STACK_OVF];
@@ -675,9 +705,12 @@ __device__ __forceinline__ void stream_body(
     const unsigned long long below = (1ull << lane) - 1ull;
     const uint32_t home = xcc_id();
     unsigned long long *heads = counters + RT_CNT_HEADS;
+    const uint32_t refill_min = tn.refill_min, finish_min = tn.finish_min, vote_node = tn.vote_node, vote_tri = tn.vote_tri, uni_min = tn.uni_min;
     // wave-uniform work-source state
     uint32_t reg_q = 0, reg_r = 0, reg_next = RT_REGION_PX;  // the wave's region and its next pixel
     uint32_t qoff = 0u;                                     // queues found empty so far (8 = all)
+    const uint32_t pool_dep = POOL ? tn.pool_dep : 0u;
+    uint32_t dep_thresh = pool_dep;                         // unfinished rays at or below which the wave tries to deposit
     Cnt c; c.nodes = 0; c.tris = 0; c.meshes = 0; c.wnodes = 0; c.wtris = 0; c.walive = 0;
     uint32_t n_primary = 0, n_shadow = 0;
     // per-lane ray
@@ -693,8 +726,49 @@ __device__ __forceinline__ void stream_body(
 #ifdef RT_DEBUG_TIMELINE
     const unsigned long long dbg_t0 = wall_clock64();
 #endif
+    // the block's lock: taken by one lane for the wave (wave-uniform control flow around it), released after the wave's LDS
+    // writes have landed
+    auto pool_lock = [&]() {
+        if (lane == 0u) {
+            while (__hip_atomic_exchange(&s_pool_lock, 1u, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != 0u) __builtin_amdgcn_s_sleep(2);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+    };
+    auto pool_unlock = [&]() {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        if (lane == 0u) __hip_atomic_store(&s_pool_lock, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    };
+    auto lds_u32 = [&](const uint32_t *p) {   // a wave-uniform read of a block variable (not cached in a register)
+        return (uint32_t)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+    };
+    // idle lanes take up to n_take pooled rays (the newest ones); call with the lock held
+    auto pool_take = [&](uint32_t n_have, uint32_t n_take, unsigned long long idle) {
+        const uint32_t r = (uint32_t)__builtin_popcountll(idle & below);
+        const bool mine = state == 0 && r < n_take;
+        const uint32_t slot = n_have - n_take + (mine ? r : 0u);
+        if (mine) {
+            o = F3(s_pool_f[0][slot], s_pool_f[1][slot], s_pool_f[2][slot]);
+            d = F3(s_pool_f[3][slot], s_pool_f[4][slot], s_pool_f[5][slot]);
+            t = s_pool_f[6][slot]; hu = s_pool_f[7][slot]; hv = s_pool_f[8][slot];
+            seq = s_pool_u[0][slot]; rec = s_pool_u[1][slot]; cur = (int)s_pool_u[2][slot]; sp = (int)s_pool_u[3][slot];
+            idx = s_pool_u[4][slot]; state = (int)s_pool_u[5][slot];
+            inv = ray_inv<WIDE>(d);
+        }
+        const int top = mine ? sp : 0;
+        for (int l = 0; l < RT_STACK_LDS; ++l) {
+            if (__ballot(l < top) == 0ull) break;
+            if (l < top) stk[l * RT_BLOCK] = s_pool_stk[l][slot];
+        }
+        if (lane == 0u) __hip_atomic_store(&s_pool_n, n_have - n_take, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    };
     for (;;) {
         // ================= service: runs when the hot loop below asks for it =================================
+        // What the service code reads of the scene / view / shard descriptions it reads from LDS HERE, every time: without
+        // this barrier the compiler loads all of it once at kernel start, into ~40 VGPRs that it then has to spill
+        // (every lane of every wave storing 176 B at start-up: 80 MB of a frame's 203 MB of writes in round 1).
+        __asm__ volatile("" ::: "memory");
         // ---- 1. finish ended rays (shade, write, start the shadow ray) -----------------------------------------
         if (cur == RT_DONE && state == 1) {
             float4 out = make_float4(0.0f, 0.0f, 0.0f, 0.0f);      // miss: vec4(0) (wgsl:210)
@@ -727,10 +801,54 @@ __device__ __forceinline__ void stream_body(
             }
             state = 0;
         }
+        bool more = qoff < 8u || reg_next < RT_REGION_PX;
+        // ---- 1b. a wave down to its last few rays deposits them in the block's pool ---------------------------------
+        bool deposited = false;
+        if (POOL && pool_dep != 0u) {
+            const unsigned long long livem = __ballot(cur != RT_DONE);
+            const uint32_t n_l = (uint32_t)__builtin_popcountll(livem);
+            if (n_l != 0u && n_l <= dep_thresh) {
+                if (__ballot(cur != RT_DONE && sp > RT_STACK_LDS) == 0ull) {      // the private part of a stack does not travel
+                    pool_lock();
+                    const uint32_t have = lds_u32(&s_pool_n), running = lds_u32(&s_running);
+                    if (have + n_l <= NP && running >= 2u && (more || tn.pool_drain != 0u)) {
+                        const bool live = cur != RT_DONE;
+                        const uint32_t slot = have + (uint32_t)__builtin_popcountll(livem & below);
+                        if (live) {
+                            s_pool_f[0][slot] = o.x; s_pool_f[1][slot] = o.y; s_pool_f[2][slot] = o.z;
+                            s_pool_f[3][slot] = d.x; s_pool_f[4][slot] = d.y; s_pool_f[5][slot] = d.z;
+                            s_pool_f[6][slot] = t; s_pool_f[7][slot] = hu; s_pool_f[8][slot] = hv;
+                            s_pool_u[0][slot] = seq; s_pool_u[1][slot] = rec; s_pool_u[2][slot] = (uint32_t)cur; s_pool_u[3][slot] = (uint32_t)sp;
+                            s_pool_u[4][slot] = idx; s_pool_u[5][slot] = (uint32_t)state;
+                        }
+                        const int top = live ? sp : 0;
+                        for (int l = 0; l < RT_STACK_LDS; ++l) {
+                            if (__ballot(l < top) == 0ull) break;
+                            if (l < top) s_pool_stk[l][slot] = stk[l * RT_BLOCK];
+                        }
+                        if (live) { cur = RT_DONE; state = 0; sp = 0; }
+                        if (lane == 0u) __hip_atomic_store(&s_pool_n, have + n_l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        deposited = true;
+                    }
+                    pool_unlock();
+                }
+                // not deposited (deep stacks, a full pool, the block's last wave): try again when half of these rays are left
+                if (!deposited) dep_thresh = n_l >> 1;
+            }
+        }
         // ---- 2. idle lanes take new work -------------------------------------------------------------------------
         unsigned long long idle = __ballot(state == 0);
         {
-            // the wave's region first; a used-up region is replaced from the XCD's queue (one atomic per 64
+            // pooled stragglers first when enough of them wait (a full wave's worth of the same kind of ray) ...
+            if (POOL && pool_dep != 0u && idle == ~0ull && more && lds_u32(&s_pool_n) >= tn.pool_pick) {
+                pool_lock();
+                const uint32_t have = lds_u32(&s_pool_n);
+                if (have >= tn.pool_pick) pool_take(have, have < 64u ? have : 64u, idle);
+                pool_unlock();
+                idle = __ballot(state == 0);
+                dep_thresh = pool_dep;
+            }
+            // ... else the wave's region; a used-up region is replaced from the XCD's queue (one atomic per 64
             // pixels), an empty queue by the next XCD's
             const bool all_idle = idle == ~0ull;
             const uint32_t rpt = (sh.tile >> 4) * (sh.tile >> 4) * 4u;   // 8x8 regions per shard tile
@@ -774,12 +892,34 @@ __device__ __forceinline__ void stream_body(
                 }
                 reg_next += (uint32_t)__builtin_popcountll(idle);   // pixels outside the image are skipped
                 idle = __ballot(state == 0);
+                dep_thresh = pool_dep;
             }
-            if (idle == ~0ull && qoff >= 8u && reg_next >= RT_REGION_PX) break;   // nothing in flight, nothing left
+            more = qoff < 8u || reg_next < RT_REGION_PX;
+            // the queues are empty: idle lanes take whatever the pool holds (the frame's end merges the block's tails) --
+            // except right after this wave's own deposit, which is for the block's other waves
+            if (POOL && pool_dep != 0u && !more && idle != 0ull && !deposited && lds_u32(&s_pool_n) != 0u) {
+                pool_lock();
+                const uint32_t have = lds_u32(&s_pool_n), n_idle_l = (uint32_t)__builtin_popcountll(idle);
+                if (have != 0u) pool_take(have, have < n_idle_l ? have : n_idle_l, idle);
+                pool_unlock();
+                idle = __ballot(state == 0);
+                dep_thresh = pool_dep;
+            }
+            if (idle == ~0ull && !more) {
+                // nothing in flight, no regions left: leave -- unless this is the block's last wave and rays wait in the pool
+                if (!POOL || pool_dep == 0u) break;
+                bool leave = true;
+                pool_lock();
+                const uint32_t have = lds_u32(&s_pool_n), running = lds_u32(&s_running);
+                if (have != 0u && running <= 1u) { pool_take(have, have < 64u ? have : 64u, idle); leave = false; }
+                else if (lane == 0u) __hip_atomic_store(&s_running, running - 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                pool_unlock();
+                if (leave) break;
+                dep_thresh = pool_dep;
+            }
         }
         if (__ballot(cur != RT_DONE) == 0ull) continue;   // only ended rays (e.g. an empty scene): service again
         // ================= hot loop: one voted step per trip, until the wave needs service ========================
-        const bool more = qoff < 8u || reg_next < RT_REGION_PX;
         const bool any = state == 2;
         // idle lanes stay idle inside the hot loop, so ended-but-unfinished rays = done - idle: two ballots a trip
         const uint32_t n_idle = (uint32_t)__builtin_popcountll(__ballot(state == 0));
@@ -851,7 +991,7 @@ __device__ __forceinline__ void stream_body(
                 return;
             }
 #endif
-        } while (!(n_live == 0u || n_pend >= finish_min || (more && n_done >= refill_min)));
+        } while (!(n_live <= dep_thresh || n_pend >= finish_min || (more && n_done >= refill_min)));
     }
 #ifdef RT_DEBUG_TIMELINE     // debug builds only (tools/timeline.py): per-wave start / end times (100 MHz) over the hit-distance output
     if (lane == 0u) {
@@ -878,12 +1018,11 @@ __device__ __forceinline__ void stream_body(
 #ifndef RT_STREAM_WAVES
 #define RT_STREAM_WAVES RT_MIN_WAVES
 #endif
-template <bool COUNT, bool WIDE>
-__global__ __launch_bounds__(RT_BLOCK, RT_STREAM_WAVES) void k_stream(
-    RtSceneDev S_, RtViewDev V_, RtShardDev sh_, uint32_t flags, uint32_t refill_min, uint32_t finish_min,
-    uint32_t vote_node, uint32_t vote_tri, uint32_t uni_min, float4 *__restrict__ rgba, uint32_t *__restrict__ prim,
+template <bool COUNT, bool WIDE, bool POOL>
+__global__ __launch_bounds__(RT_BLOCK, POOL ? (RT_STREAM_WAVES < 5 ? RT_STREAM_WAVES : 5) : RT_STREAM_WAVES) void k_stream(   // the pool's LDS leaves room for 6 blocks per CU
+    RtSceneDev S_, RtViewDev V_, RtShardDev sh_, uint32_t flags, RtStreamTune tn, float4 *__restrict__ rgba, uint32_t *__restrict__ prim,
     float *__restrict__ tout, unsigned long long *__restrict__ counters) {
-    stream_body<COUNT, WIDE>(S_, V_, sh_, flags, refill_min, finish_min, vote_node, vote_tri, uni_min, rgba, prim, tout, counters);
+    stream_body<COUNT, WIDE, POOL>(S_, V_, sh_, flags, tn, rgba, prim, tout, counters);
 }
 
 // ---- A2 RNG: ray_tracing.wgsl:38-74 (integer core; deterministic log/cos) ------------------------
@@ -1424,10 +1563,23 @@ hipError_t rtk_launch_primary(hipStream_t st, const RtSceneDev &S, const RtViewD
         uint32_t grid = tune.cus * per_cu < need ? tune.cus * per_cu : need;
         if (grid == 0) return hipSuccess;
         const bool wide = S.n_wide != 0u && !(flags & RT_FLAG_BINARY_TREE);
-#define RT_LAUNCH_STREAM(C, W, VN, VT) \
-    hipLaunchKernelGGL((k_stream<C, W>), dim3(grid), dim3(RT_BLOCK), 0, st, S, V, sh, flags, tune.refill_min, tune.finish_min, VN, VT, tune.uni_min, (float4 *)rgba, prim, t, counters)
-        if (wide) { if (count) RT_LAUNCH_STREAM(true, true, tune.wide_vote_node, tune.wide_vote_tri); else RT_LAUNCH_STREAM(false, true, tune.wide_vote_node, tune.wide_vote_tri); }
-        else { if (count) RT_LAUNCH_STREAM(true, false, tune.vote_node, tune.vote_tri); else RT_LAUNCH_STREAM(false, false, tune.vote_node, tune.vote_tri); }
+        RtStreamTune tn;
+        tn.refill_min = tune.refill_min; tn.finish_min = tune.finish_min; tn.uni_min = tune.uni_min;
+        tn.vote_node = wide ? tune.wide_vote_node : tune.vote_node; tn.vote_tri = wide ? tune.wide_vote_tri : tune.vote_tri;
+        tn.pool_dep = tune.pool_dep; tn.pool_pick = tune.pool_pick; tn.pool_drain = tune.pool_drain;
+#define RT_LAUNCH_STREAM(C, W, P) \
+    hipLaunchKernelGGL((k_stream<C, W, P>), dim3(grid), dim3(RT_BLOCK), 0, st, S, V, sh, flags, tn, (float4 *)rgba, prim, t, counters)
+        const int variant = (count ? 4 : 0) | (wide ? 2 : 0) | (tn.pool_dep != 0u ? 1 : 0);
+        switch (variant) {
+            case 0: RT_LAUNCH_STREAM(false, false, false); break;
+            case 1: RT_LAUNCH_STREAM(false, false, true); break;
+            case 2: RT_LAUNCH_STREAM(false, true, false); break;
+            case 3: RT_LAUNCH_STREAM(false, true, true); break;
+            case 4: RT_LAUNCH_STREAM(true, false, false); break;
+            case 5: RT_LAUNCH_STREAM(true, false, true); break;
+            case 6: RT_LAUNCH_STREAM(true, true, false); break;
+            default: RT_LAUNCH_STREAM(true, true, true); break;
+        }
 #undef RT_LAUNCH_STREAM
         return hipGetLastError();
     }

@@ -202,3 +202,67 @@ def test_sixteen_sample_batch_at_1080p_and_config3_four_way_shard_at_4k():
             assert np.all(part[owner != rank] == 0)
             total += part
         assert np.array_equal(total, full)
+
+
+@pytest.mark.parametrize("n", [2, 3])
+def test_frames_in_flight_inside_one_context(n):
+    """rt_set_frames_in_flight: rt_render takes n sets of frame buffers / streams in turn without waiting for the frame
+    before.  Every frame must still be the serial frame, bit for bit, readers must see the frame rendered last, a scene
+    update must wait for the frames in flight, and path-traced frames (one shared accumulation buffer) must not overlap."""
+    app = soup_app(200, 0x5EED0003, 640, 360)
+    app.camera_frame_scene(1.0)
+    scene = app.prepare_meshinfo()
+    cams = []
+    for k in range(7):
+        app.camera_look_at((30.0 * np.cos(k), 25.0 + 3 * k, 30.0 * np.sin(k)), (0, 0, 0), (0, 1, 0))
+        cams.append(app.camera_view())
+    with rt.Context(0) as ctx:
+        ctx.upload_scene(scene)
+        serial = []
+        for m, p in cams:
+            ctx.set_view(m, p, 640, 360)
+            ctx.render(flags=rt.FLAG_SHADOW | rt.FLAG_COUNTERS)
+            c = ctx.counters()
+            serial.append((ctx.read_radiance(), ctx.read_prim_ids(), ctx.read_hit_t(), (c.rays_primary, c.rays_shadow, c.node_visits, c.tri_tests)))
+        ctx.set_frames_in_flight(n)
+        for rep in range(2):
+            for k, (m, p) in enumerate(cams):                          # frames queued back to back, read only at the end of a burst
+                ctx.set_view(m, p, 640, 360)
+                ctx.render(flags=rt.FLAG_SHADOW | rt.FLAG_COUNTERS)
+                if k % 3 == 2 or k == len(cams) - 1:
+                    c = ctx.counters()
+                    assert bitwise_equal(ctx.read_radiance(), serial[k][0]) and bitwise_equal(ctx.read_prim_ids(), serial[k][1])
+                    assert bitwise_equal(ctx.read_hit_t(), serial[k][2])
+                    assert (c.rays_primary, c.rays_shadow, c.node_visits, c.tri_tests) == serial[k][3]
+        # a tile shard on every set: pixels of other ranks' tiles read as cleared whichever set the frame lands on
+        m, p = cams[0]
+        ctx.set_view(m, p, 640, 360)
+        own = multi_gpu.tile_owner(640, 360, 64, 3) == 1
+        for _ in range(n + 1):
+            ctx.render(flags=rt.FLAG_SHADOW, shard_rank=1, shard_count=3, tile_size=64)
+            part = ctx.read_radiance()
+            assert bitwise_equal(part[own], serial[0][0][own]) and np.all(part[~own] == 0)
+        # path tracing between overlapped frames: running sums as in a serial context
+        ctx.render(flags=rt.FLAG_SHADOW)
+        ctx.render(flags=rt.FLAG_PATH_TRACE, spp=3, max_segments=4, seed=4)
+        ctx.render(flags=rt.FLAG_SHADOW)
+        ctx.render(flags=rt.FLAG_PATH_TRACE | rt.FLAG_ACCUMULATE, spp=2, sample_first=3, max_segments=4, seed=4)
+        acc = ctx.read_accumulation()
+        acc_o, _ = orc.render_path(oracle_scene(scene), orc.make_view(m, p, 640, 360), 5, 4, seed=4, threads=16)
+        assert bitwise_equal(acc, acc_o)
+        # a vertex update while frames are in flight: the next frame sees the moved scene, the one before it did not
+        v2 = scene.vertices.copy()
+        v2["pos"][:, 1] += np.float32(0.75)
+        moved = rt.Scene(scene.triangles, scene.meshes, v2, scene.materials)
+        mm = moved.meshes.copy(); mm["aabb_min"][:, 1] += np.float32(0.75); mm["aabb_max"][:, 1] += np.float32(0.75)
+        moved = rt.Scene(scene.triangles, mm, v2, scene.materials)
+        ctx.render(flags=rt.FLAG_SHADOW)
+        ctx.render(flags=rt.FLAG_SHADOW)
+        ctx.update_vertices(moved)
+        ctx.render(flags=rt.FLAG_SHADOW)
+        after = ctx.read_prim_ids()
+        ctx.set_frames_in_flight(1)
+        ctx.render(flags=rt.FLAG_SHADOW)
+        assert bitwise_equal(ctx.read_prim_ids(), after) and not bitwise_equal(after, serial[0][1])
+        with pytest.raises(rt.RtError):
+            ctx.set_frames_in_flight(5)

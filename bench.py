@@ -91,7 +91,7 @@ def cpu_baseline(orc, scene, view, W, H, flags, target_seconds=15.0):
     perm = rng.permutation(W * H).astype(np.uint32)
     oflags = orc.FLAG_SHADOW if flags & 1 else 0
     # calibrate on a small slice, then size the sample for ~target_seconds
-    n0 = min(len(perm), 64 * threads)
+    n0 = min(len(perm), 512 * threads)
     t0 = time.perf_counter()
     orc.render_primary(osc, view, oflags, threads=threads, pixel_list=perm[:n0])
     dt0 = max(time.perf_counter() - t0, 1e-6)
@@ -289,7 +289,7 @@ def main():
         elif flags & rt.FLAG_WAVE_TRAVERSAL:
             kernel = "k_primary<false, true>"
         else:
-            kernel = f"k_stream<false, {'true' if wide else 'false'}>"
+            kernel = f"k_stream<false, {'true' if wide else 'false'}, {'true' if os.environ.get('RT_TUNE_POOL_DEP', '0') not in ('', '0') else 'false'}>"
         # Counters of the committed PMC passes (profiles/pmc_traffic.json; rocprofv3 --pmc cannot run inside this process):
         # quoted only for the workload AND the very kernel binary they were collected on -- the file records the kernel's
         # symbol, registers, spills and the hash of the device code object (tools/kernel_resources.py); a library built

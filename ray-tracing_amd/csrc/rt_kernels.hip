@@ -1125,9 +1125,10 @@ __device__ __forceinline__ bool path_scatter(const RtSceneDev &S, const Hit &h, 
         return true;
     }
     f3 l = mul(F3(0.5f, 0.71f, 0.86f), col);      // sky (wgsl:197)
-    float4 a = *acc;
-    a.x = a.x + l.x; a.y = a.y + l.y; a.z = a.z + l.z;
-    *acc = a;
+    // light = vec3(0) + sky * col: the path's slot of the contribution plane holds (0, 0, 0, 1) since k_path_start (one
+    // path per pixel and sample slot, no emission on the way: this is its only light), so the sum is formed from the
+    // constant instead of an uncoalesced 16-B read -- the same addition, the same bits (0 + x keeps -0 apart from +0)
+    *acc = make_float4(0.0f + l.x, 0.0f + l.y, 0.0f + l.z, 1.0f);
     return false;
 }
 

@@ -166,8 +166,8 @@ int rt_synchronize(rt_ctx *ctx);
  *     samples it holds is kept in the context.
  *   - keeps the frame's scratch (work-queue heads, counters, path queues, contribution plane) in a static device
  *     array of RT_STATIC_SCRATCH_BYTES = 32 MiB that every GPU the library runs on holds until the process ends.
- *     Primary / shadow frames use 1.2 KB of it at any frame size; path tracing uses 104 B per pixel (one sample per
- *     launch), so frames beyond RT_STATIC_MAX_PATH_PIXELS (322,560; 640x360 fits) return RT_ERR_ARG with a message
+ *     Primary / shadow frames use 1.2 KB of it at any frame size; path tracing uses 120 B per pixel (one sample per
+ *     launch), so frames beyond RT_STATIC_MAX_PATH_PIXELS (279,552; 640x360 fits) return RT_ERR_ARG with a message
  *     that says so.  RT_FLAG_TIME_KERNELS is refused (it creates events).
  *   - calls no hipMalloc / hipFree / hipEventCreate or any other allocating routine, first call included (scene and
  *     view are set up beforehand with rt_upload_scene / rt_set_view, which do allocate).
@@ -175,7 +175,7 @@ int rt_synchronize(rt_ctx *ctx);
  * array: calls that overlap on one GPU (two contexts, two streams) race -- serialise them.  The array keeps the last
  * call's contents; what must start at zero is cleared by the call itself. */
 #define RT_STATIC_SCRATCH_BYTES   (32u << 20)
-#define RT_STATIC_MAX_PATH_PIXELS 322560u
+#define RT_STATIC_MAX_PATH_PIXELS 279552u
 int rt_render_static(rt_ctx *ctx, const rt_render_params *params, void *d_radiance, void *d_prim_ids, void *d_hit_t,
                      void *d_accum, size_t n_pixels);
 

@@ -108,7 +108,7 @@ extern "C" {
     pub fn rt_render(ctx: *mut rt_ctx, params: *const rt_render_params) -> c_int;
     pub fn rt_synchronize(ctx: *mut rt_ctx) -> c_int;
     /// The same frame into the caller's device buffers, allocating nothing (scratch in a static 32 MiB device array;
-    /// path tracing up to 322,560 pixels; calls that overlap on one GPU race).
+    /// path tracing up to 279,552 pixels; calls that overlap on one GPU race).
     pub fn rt_render_static(ctx: *mut rt_ctx, params: *const rt_render_params, d_radiance: *mut c_void, d_prim_ids: *mut c_void,
         d_hit_t: *mut c_void, d_accum: *mut c_void, n_pixels: usize) -> c_int;
     pub fn rt_read_radiance(ctx: *mut rt_ctx, rgba: *mut f32, n_floats: usize) -> c_int;

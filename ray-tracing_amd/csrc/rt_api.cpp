@@ -87,6 +87,7 @@ struct rt_ctx {
     size_t q_capacity = 0;
     float *d_contrib = nullptr;
     uint32_t contrib_planes = 0;
+    float *d_hits = nullptr;              // one 16-B hit record per queued path (k_path_trace -> k_path_shade)
 
     // counters
     unsigned long long *d_cnt = nullptr;
@@ -174,6 +175,7 @@ void free_frame(rt_ctx *c) {
     }
     c->q_capacity = 0;
     p = c->d_contrib; free_dev(p); c->d_contrib = nullptr; c->contrib_planes = 0;
+    p = c->d_hits; free_dev(p); c->d_hits = nullptr;
     c->n_px = 0;
 }
 
@@ -206,10 +208,12 @@ int ensure_queues(rt_ctx *c, uint32_t batch) {
             p = c->q[i].u; free_dev(p); c->q[i].u = nullptr;
         }
         c->q_capacity = 0;
+        { void *p = c->d_hits; free_dev(p); c->d_hits = nullptr; }
         for (int i = 0; i < 2; ++i) {
             HIPCHK(c, hipMalloc((void **)&c->q[i].f, need * 9 * sizeof(float)));
             HIPCHK(c, hipMalloc((void **)&c->q[i].u, need * 2 * sizeof(uint32_t)));
         }
+        HIPCHK(c, hipMalloc((void **)&c->d_hits, need * 16));
         c->q_capacity = need;
     }
     if (c->contrib_planes < batch || !c->d_contrib) {
@@ -281,6 +285,8 @@ int rt_create(int device_ordinal, rt_ctx **out) {
         c->tune.pool_dep = env("RT_TUNE_POOL_DEP", 0, 0, 32);
         c->tune.pool_pick = env("RT_TUNE_POOL_PICK", 40, 1, 64);
         c->tune.pool_drain = env("RT_TUNE_POOL_DRAIN", 0, 0, 1);
+        c->tune.path_split = env("RT_TUNE_PATH_SPLIT", 0, 0, 1);
+        c->tune.path_refill_min = env("RT_TUNE_PATH_REFILL_MIN", 16, 1, 64);
         c->tune_wide = env("RT_TUNE_WIDE", 1, 0, 1);
         c->tune_sample_batch = env("RT_TUNE_SAMPLE_BATCH", 16, 1, 16);
     }
@@ -857,6 +863,7 @@ struct RenderTargets {
     unsigned long long *cnt;       // counters + work-queue heads (RT_CNT_N words)
     RtPathQueue qa, qb;            // path queues, capacity q_cap paths each
     float *contrib;                // per-sample contribution planes: max_batch planes of n_px float4
+    float *hits;                   // one float4 per queued path
     size_t q_cap;
     uint32_t max_batch;            // most samples of a pixel traced per launch (16, 4 or 1)
 };
@@ -933,10 +940,16 @@ static int launch_frame(rt_ctx *c, const rt_render_params &P, const RtShardDev &
             int in = RT_CNT_QUEUE_A, out = RT_CNT_QUEUE_B;
             for (uint32_t seg = 1; seg < P.max_segments; ++seg) {
                 HIPCHK(c, hipMemsetAsync(T.cnt + out, 0, sizeof(unsigned long long), c->stream));
-                HIPCHK(c, rtk_launch_path_bounce(c->stream, c->S, P.flags, cap, seg + 1 == P.max_segments, T.contrib, (uint32_t)c->n_px,
-                                                 in == RT_CNT_QUEUE_A ? T.qa : T.qb, in == RT_CNT_QUEUE_A ? T.qb : T.qa,
-                                                 T.cnt, in, out, c->tune));
-                ++launches;
+                const bool split = c->tune.path_split && !(P.flags & (RT_FLAG_BRUTE_FORCE | RT_FLAG_STATIC_GRID));
+                if (split)
+                    HIPCHK(c, rtk_launch_path_trace_shade(c->stream, c->S, P.flags, cap, seg + 1 == P.max_segments, T.contrib, (uint32_t)c->n_px,
+                                                          in == RT_CNT_QUEUE_A ? T.qa : T.qb, T.hits, in == RT_CNT_QUEUE_A ? T.qb : T.qa,
+                                                          T.cnt, in, out, c->tune));
+                else
+                    HIPCHK(c, rtk_launch_path_bounce(c->stream, c->S, P.flags, cap, seg + 1 == P.max_segments, T.contrib, (uint32_t)c->n_px,
+                                                     in == RT_CNT_QUEUE_A ? T.qa : T.qb, in == RT_CNT_QUEUE_A ? T.qb : T.qa,
+                                                     T.cnt, in, out, c->tune));
+                launches += split ? 2u : 1u;
                 int tmp = in; in = out; out = tmp;
             }
             HIPCHK(c, rtk_launch_accumulate_batch(c->stream, T.accum, T.contrib, c->n_px, b));
@@ -987,6 +1000,7 @@ int rt_render(rt_ctx *c, const rt_render_params *params) {
         T.max_batch = std::min(c->tune_sample_batch, c->contrib_planes);
         T.qa = queue_view(c->q[0], c->q_capacity); T.qb = queue_view(c->q[1], c->q_capacity);
         T.contrib = c->d_contrib;
+        T.hits = c->d_hits;
         // the running sums restart unless asked to go on -- and also when the camera or the geometry moved or the coverage
         // is not the one they were started under (intent of src/scene.rs:94-96)
         if (!(P.flags & RT_FLAG_ACCUMULATE) || c->accum_dirty || std::memcmp(cov, c->accum_cov, sizeof cov) != 0) {
@@ -1027,7 +1041,7 @@ int rt_render(rt_ctx *c, const rt_render_params *params) {
 // up once (c->static_scratch).  No hipMalloc / hipFree / hipEventCreate on this path, first call included.
 namespace {
 constexpr size_t kStaticCntBytes = 4096;                                   // RT_CNT_N * 8 = 1152 B, rounded up
-constexpr size_t kStaticPathBytesPerPx = 2 * 11 * 4 + 16;                  // two queues of 11 dwords + one float4 plane
+constexpr size_t kStaticPathBytesPerPx = 2 * 11 * 4 + 16 + 16;             // two queues of 11 dwords + one float4 plane + one hit record
 constexpr size_t kStaticAlignSlack = 16 * 256;                             // every sub-buffer starts on a 256-B boundary
 constexpr size_t kStaticMaxPathPx = (RT_STATIC_SCRATCH_BYTES - kStaticCntBytes - kStaticAlignSlack) / kStaticPathBytesPerPx;
 static_assert(kStaticMaxPathPx == RT_STATIC_MAX_PATH_PIXELS, "include/rt_amd.h documents this limit");
@@ -1064,6 +1078,7 @@ int rt_render_static(rt_ctx *c, const rt_render_params *params, void *d_radiance
         QueueMem q[2];
         for (int i = 0; i < 2; ++i) { q[i].f = (float *)take(c->n_px * 9 * 4); q[i].u = (uint32_t *)take(c->n_px * 2 * 4); }
         T.contrib = (float *)take(c->n_px * 16);
+        T.hits = (float *)take(c->n_px * 16);
         if (off > RT_STATIC_SCRATCH_BYTES) return fail(c, RT_ERR_ARG, "rt_render_static: frame does not fit the static scratch array");
         T.qa = queue_view(q[0], c->n_px); T.qb = queue_view(q[1], c->n_px);
         T.q_cap = c->n_px; T.max_batch = 1;               // one sample per launch: same sums, bit for bit

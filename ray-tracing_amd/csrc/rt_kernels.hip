@@ -1255,6 +1255,160 @@ __global__ __launch_bounds__(RT_BLOCK, RT_MIN_WAVES) void k_path_bounce(RtSceneD
     }
 }
 
+// ---- bounce segments, split (round 2): k_path_trace walks, k_path_shade scatters -------------------------------------
+// k_path_bounce keeps a wave on its 64 paths until the LONGEST of their segments has ended (its VALU instructions run
+// with 36 % of the lanes; profiles/r2/pmc_path_*.txt), and every attempt to refill lanes inside it also ran the scatter
+// code -- three Box-Muller normals, ~400 instructions -- for a handful of lanes at a time.  Here the two halves of a segment
+// are separate launches: k_path_trace is a persistent kernel whose lanes are refilled from the queue as their rays end
+// (bounce rays are incoherent, there is no lockstep to lose, and a refill is six loads), and writes one 16-B hit record
+// per path; k_path_shade then reads queue + hit records with all lanes busy, scatters and compacts.  A path's arithmetic
+// is unchanged (the same traversal steps in the same order, the same path_scatter), so the sums are bit-identical; only
+// the ORDER of the next queue changes, which nothing depends on (one contribution slot per path).
+#define RT_TRACE_CHUNK 256u         // paths a wave takes per atomic on the work counter
+template <bool COUNT, bool WIDE>
+__global__ __launch_bounds__(RT_BLOCK, RT_MIN_WAVES) void k_path_trace(
+    const RtBvhNode *__restrict__ nodes_, const RtTriRecord *__restrict__ recs, const rt_mesh_info *__restrict__ meshes, uint32_t n_nodes,
+    uint32_t flags, RtPathQueue qi, float4 *__restrict__ hits, unsigned long long *__restrict__ counters, int qi_ctr,
+    uint32_t refill_min, uint32_t vote_node, uint32_t vote_tri) {
+    __shared__ int s_stack[RT_STACK_LDS * RT_BLOCK];
+    lds_int *stk = (lds_int *)(s_stack + threadIdx.x);
+    int ovf_mem[RT_STACK_OVF];
+    prv_int *ovf = (prv_int *)ovf_mem;
+    const RtBvhNode *const nodes = nodes_;
+    const uint32_t n = (uint32_t)counters[qi_ctr];
+    const uint32_t lane = threadIdx.x & 63u;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    unsigned long long *work = counters + RT_CNT_WORK;
+    uint32_t chunk_next = 0u, chunk_end = 0u;      // wave-uniform: the wave's share of the queue not handed to a lane yet
+    bool more = n != 0u && n_nodes != 0u;
+    Cnt c; c.nodes = 0; c.tris = 0; c.meshes = 0; c.wnodes = 0; c.wtris = 0; c.walive = 0;
+    f3 o = F3(0.0f, 0.0f, 0.0f), d = F3(0.0f, 0.0f, 1.0f), inv = F3(0.0f, 0.0f, 1.0f);
+    float t = RT_INF, hu = 0.0f, hv = 0.0f;
+    uint32_t seq = 0xFFFFFFFFu, rec = 0xFFFFFFFFu, my = 0u;
+    int cur = RT_DONE, sp = 0;
+    bool busy = false;             // the lane holds a path whose hit record is not written yet
+    for (;;) {
+        // ---- service: ended rays leave their hit record, idle lanes take the next paths of the wave's chunk -----------
+        if (busy && cur == RT_DONE) {
+            hits[my] = make_float4(t, hu, hv, __uint_as_float(rec));
+            busy = false;
+        }
+        unsigned long long idle = __ballot(!busy);
+        while (idle && more) {
+            if (chunk_next >= chunk_end) {
+                uint32_t b = 0u;
+                if (lane == 0u) b = (uint32_t)atomicAdd(work, (unsigned long long)RT_TRACE_CHUNK);
+                b = (uint32_t)__builtin_amdgcn_readfirstlane((int)b);
+                if (b >= n) { more = false; break; }
+                chunk_next = b; chunk_end = b + RT_TRACE_CHUNK < n ? b + RT_TRACE_CHUNK : n;
+            }
+            const uint32_t i = chunk_next + (uint32_t)__builtin_popcountll(idle & below);
+            if (!busy && i < chunk_end) {
+                o = F3(qi.ox[i], qi.oy[i], qi.oz[i]);
+                d = F3(qi.dx[i], qi.dy[i], qi.dz[i]);
+                inv = ray_inv<WIDE>(d);
+                t = RT_INF; hu = 0.0f; hv = 0.0f; seq = 0xFFFFFFFFu; rec = 0xFFFFFFFFu;
+                cur = ray_has_nan(o, d) ? RT_DONE : 0; sp = 0;
+                my = i; busy = true;
+            }
+            const uint32_t took = (uint32_t)__builtin_popcountll(idle);
+            chunk_next = chunk_next + took < chunk_end ? chunk_next + took : chunk_end;
+            idle = __ballot(!busy);
+        }
+        if (__ballot(busy) == 0ull) break;                 // nothing in flight and nothing left to take
+        if (__ballot(cur != RT_DONE) == 0ull) continue;    // only rays that ended at once (NaN): write them, take more
+        // ---- hot loop: one voted step per trip (the loop of stream_body / traverse<>) -----------------------------------
+        uint32_t n_done, n_live;
+        do {
+            const unsigned long long m_node = __ballot(cur >= 0);
+            const uint32_t n_node = (uint32_t)__builtin_popcountll(m_node);
+            n_done = (uint32_t)__builtin_popcountll(__ballot(cur == RT_DONE));
+            const uint32_t n_leaf = 64u - n_done - n_node;
+            if (n_node * vote_tri >= n_leaf * vote_node) {
+                if (cur >= 0) {
+                    const float4 *p = reinterpret_cast<const float4 *>(nodes + cur);
+                    float4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3];
+                    if (COUNT) { c.nodes++; if (lane == (uint32_t)__builtin_ctzll(m_node)) { c.wnodes++; c.walive += n_node + n_leaf; } }
+                    if (WIDE) wide_decide(q0, q1, q2, q3, o, inv, t, cur, sp, stk, ovf);
+                    else node_decide(q0, q1, q2, q3, o, inv, t, cur, sp, stk, ovf);
+                }
+            } else {
+                if (cur < 0 && cur != RT_DONE) {
+                    if (cur == RT_CHILD_NONE) cur = stack_pop(sp, stk, ovf);
+                    else {
+                        uint32_t code = (uint32_t)(~cur);
+                        uint32_t first = code >> 3, left = code & 7u;
+                        const float4 *r = reinterpret_cast<const float4 *>(recs + first);
+                        float4 r0 = r[0], r1 = r[1], r2 = r[2];
+                        if (COUNT) { c.tris++; if (lane == (uint32_t)__builtin_ctzll(__ballot(true))) c.wtris++; }
+                        float dst, u, v;
+                        bool ok = prim_test(o, d, r0, r1, r2, dst, u, v);
+                        uint32_t sq = __float_as_uint(r2.w);
+                        ok = ok && (dst < t || (dst == t && sq < seq));
+                        if (ok && !(flags & RT_FLAG_NO_MESH_CULL) && __float_as_uint(r2.z) != RT_REC_SPHERE) {   // per-mesh AABB cull of wgsl:155
+                            const float4 *mp = reinterpret_cast<const float4 *>(meshes + __float_as_uint(r2.z));
+                            float4 m1 = mp[1], m2 = mp[2];
+                            ok = ray_aabb_ref(o, exact_inv<WIDE>(inv, d), F3(m1.x, m1.y, m1.z), F3(m2.x, m2.y, m2.z));
+                            if (COUNT) c.meshes++;
+                        }
+                        if (ok) { t = dst; seq = sq; rec = first; hu = u; hv = v; }
+                        if (left == 0u) cur = stack_pop(sp, stk, ovf);
+                        else cur = ~(int)(((first + 1u) << 3) | (left - 1u));
+                    }
+                }
+            }
+            n_done = (uint32_t)__builtin_popcountll(__ballot(cur == RT_DONE));
+            n_live = 64u - n_done;
+        } while (!(n_live == 0u || (more && n_done >= refill_min)));
+    }
+    if (COUNT) {
+        wave_sum(counters + RT_CNT_NODES, c.nodes);
+        wave_sum(counters + RT_CNT_TRIS, c.tris);
+        wave_sum(counters + RT_CNT_MESH, c.meshes);
+        wave_sum(counters + RT_CNT_WNODE, c.wnodes);
+        wave_sum(counters + RT_CNT_WTRI, c.wtris);
+        wave_sum(counters + RT_CNT_WALIVE, c.walive);
+    }
+}
+
+// the other half of a bounce segment: scatter (or add the sky and end), compact the survivors into the next queue
+__global__ __launch_bounds__(RT_BLOCK) void k_path_shade(RtSceneDev S, int is_last, float4 *__restrict__ contrib, uint32_t n_px, RtPathQueue qi,
+                                                         const float4 *__restrict__ hits, RtPathQueue qo,
+                                                         unsigned long long *__restrict__ counters, int qi_ctr, int qo_ctr) {
+    const uint32_t n = (uint32_t)counters[qi_ctr];
+    uint32_t n_bounce = 0;
+    for (uint32_t vb = blockIdx.x; vb * RT_BLOCK < n; vb += gridDim.x) {
+        const uint32_t i = vb * RT_BLOCK + threadIdx.x;
+        bool alive = false;
+        f3 o, d, col; uint32_t rng = 0, pixel = 0;
+        if (i < n) {
+            o = F3(qi.ox[i], qi.oy[i], qi.oz[i]);
+            d = F3(qi.dx[i], qi.dy[i], qi.dz[i]);
+            const float4 hr = hits[i];
+            Hit h;
+            h.t = hr.x; h.u = hr.y; h.v = hr.z; h.seq = 0u; h.tri = 0xFFFFFFFFu; h.mesh = 0u;
+            const uint32_t rec = __float_as_uint(hr.w);
+            h.hit = rec != 0xFFFFFFFFu;
+            if (h.hit) {
+                float4 r2 = reinterpret_cast<const float4 *>(S.recs + rec)[2];
+                h.tri = __float_as_uint(r2.y); h.mesh = __float_as_uint(r2.z);
+            }
+            col = F3(qi.cr[i], qi.cg[i], qi.cb[i]);
+            rng = qi.rng[i]; pixel = qi.pixel[i];                // pixel | sample slot << RT_PATH_SLOT_SHIFT
+            alive = path_scatter(S, h, o, d, col, rng, contrib + (size_t)(pixel >> RT_PATH_SLOT_SHIFT) * n_px + (pixel & RT_PATH_PIXEL_MASK)) && !is_last;
+            ++n_bounce;
+        }
+        uint32_t slot = queue_slot(counters + qo_ctr, alive);
+        if (alive) {
+            qo.ox[slot] = o.x; qo.oy[slot] = o.y; qo.oz[slot] = o.z;
+            qo.dx[slot] = d.x; qo.dy[slot] = d.y; qo.dz[slot] = d.z;
+            qo.cr[slot] = col.x; qo.cg[slot] = col.y; qo.cb[slot] = col.z;
+            qo.rng[slot] = rng; qo.pixel[slot] = pixel;
+        }
+    }
+    wave_sum(counters + RT_CNT_BOUNCE, n_bounce);
+}
+
 // ---- f1 refit on the GPU: vertices moved, topology unchanged -----------------------------
 // One launch per tree level, deepest first (children are finished before their parent reads them; a kernel
 // boundary on one stream is the only ordering needed).  A thread owns one node of the level: for a LEAF child
@@ -1623,6 +1777,31 @@ hipError_t rtk_launch_path_bounce(hipStream_t st, const RtSceneDev &S, uint32_t 
         hipLaunchKernelGGL(k_path_bounce<true>, dim3(grid), dim3(RT_BLOCK), 0, st, S, flags, is_last, (float4 *)contrib, n_px, qin, qout, counters, qin_counter, qout_counter, persist);
     else
         hipLaunchKernelGGL(k_path_bounce<false>, dim3(grid), dim3(RT_BLOCK), 0, st, S, flags, is_last, (float4 *)contrib, n_px, qin, qout, counters, qin_counter, qout_counter, persist);
+    return hipGetLastError();
+}
+
+
+hipError_t rtk_launch_path_trace_shade(hipStream_t st, const RtSceneDev &S, uint32_t flags, uint32_t capacity, int is_last, float *contrib,
+                                       uint32_t n_px, RtPathQueue qin, float *hits, RtPathQueue qout, unsigned long long *counters,
+                                       int qin_counter, int qout_counter, const RtTune &tune) {
+    uint32_t nb = (capacity + RT_BLOCK - 1) / RT_BLOCK;
+    if (nb == 0) return hipSuccess;
+    const bool wide = S.n_wide != 0u && !(flags & RT_FLAG_BINARY_TREE);
+    const RtBvhNode *nodes = wide ? reinterpret_cast<const RtBvhNode *>(S.wide) : S.nodes;
+    const uint32_t n_nodes = wide ? S.n_wide : S.n_nodes;
+    const uint32_t vn = wide ? tune.wide_vote_node : tune.vote_node, vt = wide ? tune.wide_vote_tri : tune.vote_tri;
+    uint32_t grid = tune.persist_blocks < nb ? tune.persist_blocks : nb;
+    hipError_t e = hipMemsetAsync(counters + RT_CNT_WORK, 0, sizeof(unsigned long long), st);
+    if (e != hipSuccess) return e;
+    const bool count = (flags & RT_FLAG_COUNTERS) != 0;
+#define RT_LAUNCH_TRACE(C, W) \
+    hipLaunchKernelGGL((k_path_trace<C, W>), dim3(grid), dim3(RT_BLOCK), 0, st, nodes, S.recs, S.meshes, n_nodes, flags, qin, (float4 *)hits, counters, qin_counter, tune.path_refill_min, vn, vt)
+    if (count) { if (wide) RT_LAUNCH_TRACE(true, true); else RT_LAUNCH_TRACE(true, false); }
+    else { if (wide) RT_LAUNCH_TRACE(false, true); else RT_LAUNCH_TRACE(false, false); }
+#undef RT_LAUNCH_TRACE
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+    uint32_t sgrid = nb < tune.cus * 8u ? nb : tune.cus * 8u;
+    hipLaunchKernelGGL(k_path_shade, dim3(sgrid), dim3(RT_BLOCK), 0, st, S, is_last, (float4 *)contrib, n_px, qin, (const float4 *)hits, qout, counters, qin_counter, qout_counter);
     return hipGetLastError();
 }
 

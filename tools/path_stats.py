@@ -10,9 +10,9 @@ for name, n, seed, W, H, segs in (("soup1M_4K", 1389, 0x5EED0003, 3840, 2160, 4)
     for s in range(1, segs + 1):
         ctx.render(flags=rt.FLAG_PATH_TRACE | rt.FLAG_COUNTERS, spp=1, max_segments=s, seed=1); c = ctx.counters()
         rays = c.rays_primary + c.rays_bounce
-        print(name, "segments<=%d rays %d nodes/ray %.1f tris/ray %.2f alive %.2f util node %.2f tri %.2f" % (
+        print(name, "segments<=%d rays %d nodes/ray %.1f tris/ray %.2f alive %.2f util node %.2f tri %.2f wave trips node %d tri %d" % (
             s, rays, c.node_visits / rays, c.tri_tests / rays, c.wave_alive_lanes / max(1, 64 * c.wave_node_iters),
-            c.node_visits / max(1, 64 * c.wave_node_iters), c.tri_tests / max(1, 64 * c.wave_tri_iters)), flush=True)
+            c.node_visits / max(1, 64 * c.wave_node_iters), c.tri_tests / max(1, 64 * c.wave_tri_iters), c.wave_node_iters, c.wave_tri_iters), flush=True)
     for _ in range(2): ctx.render(flags=rt.FLAG_PATH_TRACE, spp=1, max_segments=segs, seed=1)
     ctx.counters()
     for _ in range(5): ctx.render(flags=rt.FLAG_PATH_TRACE | rt.FLAG_TIME_KERNELS, spp=1, max_segments=segs, seed=1)

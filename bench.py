@@ -197,8 +197,8 @@ def main():
     spp, segs = (wl[5], wl[6]) if len(wl) > 5 else (0, 0)
     flags = (rt.FLAG_PATH_TRACE if spp else rt.FLAG_SHADOW) | args.extra_flags
     shard = dict(shard_rank=rank, shard_count=world, tile_size=64) if tiles else {}
-    if spp:
-        shard.update(spp=spp, max_segments=segs, seed=1, stream_id=rank)
+    if spp:   # one frame sharded by tiles: every rank the same RNG stream (the frame of one GPU); own cameras: own streams
+        shard.update(spp=spp, max_segments=segs, seed=1, stream_id=0 if tiles else rank)
     if samples:   # one frame, rank r renders samples [r*spp, (r+1)*spp) of the same RNG stream
         shard.update(sample_first=rank * spp, stream_id=0)
 

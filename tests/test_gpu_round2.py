@@ -307,3 +307,35 @@ def test_measured_opt_in_variants_stay_bit_identical(env, monkeypatch):
         for _ in range(3):
             assert ctx.render(flags=rt.FLAG_SHADOW) == rt.RT_OK
             assert bitwise_equal(ctx.read_prim_ids(), prim_o) and bitwise_equal(ctx.read_radiance(), rgba_o)
+
+
+def test_config4_sample_slices_sum_to_the_unsliced_frame():
+    """configs[4] (sample slicing): the 10 M-triangle scene, <= 8 segments, 8 samples per pixel rendered as EIGHT
+    slices of one sample each (sample_first = r, one RNG stream: what rank r of 8 renders), their running sums added in rank
+    order -- SampleReduce's order -- against ONE context doing all 8 samples, and that against the oracle's walk.  One sample per
+    slice keeps the additions in the same order, so here the sum is bit-identical, not merely inside the RMSE gate; slices of
+    two samples (4 ranks) change the order: RMSE gate."""
+    app = soup_app(13889, 0x5EED0005, 960, 540)
+    app.camera_frame_scene(1.0)
+    scene = app.prepare_meshinfo()
+    assert len(scene.triangles) == 10000080
+    with rt.Context(0) as ctx:
+        ctx.upload_scene(scene)
+        m, p = app.camera_view()
+        ctx.set_view(m, p, 960, 540)
+        assert ctx.render(flags=rt.FLAG_PATH_TRACE, spp=8, max_segments=8, seed=6) == rt.RT_OK
+        full = ctx.read_accumulation()
+        tree = orc.Tree(*ctx.read_bvh(), ctx.read_bvh_wide())
+        acc_w, _, _ = orc.render_path_tree(oracle_scene(scene), tree, oracle_view(app), spp=8, max_segments=8, seed=6, threads=16)
+        assert bitwise_equal(full, acc_w)
+        total = np.zeros_like(full)
+        for r in range(8):
+            assert ctx.render(flags=rt.FLAG_PATH_TRACE, spp=1, sample_first=r, max_segments=8, seed=6, stream_id=0) == rt.RT_OK
+            total = total + ctx.read_accumulation()                       # rank order, as SampleReduce adds the slices
+        assert bitwise_equal(total, full)
+        total2 = np.zeros_like(full)
+        for r in range(4):
+            assert ctx.render(flags=rt.FLAG_PATH_TRACE, spp=2, sample_first=2 * r, max_segments=8, seed=6, stream_id=0) == rt.RT_OK
+            total2 = total2 + ctx.read_accumulation()
+        d = (total2.astype(np.float64) - full.astype(np.float64)) / 8.0
+        assert float(np.sqrt(np.mean(d * d))) <= 1e-3 and np.all(total2[..., 3] == 8.0)

@@ -6,7 +6,7 @@ describes the library that is actually loaded.
     python tools/kernel_resources.py [path/to/librt_amd.so] [substring ...]
 
 Also the source of the stale-profile guard: `fingerprint(so, kernel)` = kernel symbol + its register / spill / scratch
-figures + a hash of the whole device ELF.  profiles/pmc_traffic.json records it when the PMC passes are summarised;
+figures + a hash of that kernel's machine code.  profiles/pmc_traffic.json records it when the PMC passes are summarised;
 bench.py quotes those counters only while the loaded library still has that fingerprint.
 """
 import hashlib
@@ -76,12 +76,39 @@ def kernel_table(so_path=DEFAULT_SO):
     raise RuntimeError("no AMDGPU metadata note in the device ELF")
 
 
+def kernel_code_hashes(so_path=DEFAULT_SO):
+    """{kernel symbol: sha256[:16] of its machine code} from the device ELF's symbol table (STT_FUNC symbols)."""
+    elf = device_elf(so_path)
+    shoff, = struct.unpack_from("<Q", elf, 0x28)
+    shentsize, shnum = struct.unpack_from("<HH", elf, 0x3A)
+    secs = []
+    for i in range(shnum):
+        sh = shoff + i * shentsize
+        name, typ, flags, addr, off, size, link, info, align, entsize = struct.unpack_from("<IIQQQQIIQQ", elf, sh)
+        secs.append(dict(type=typ, addr=addr, off=off, size=size, link=link, entsize=entsize))
+    out = {}
+    for sec in secs:
+        if sec["type"] != 2:        # SHT_SYMTAB
+            continue
+        strtab = secs[sec["link"]]
+        for k in range(sec["size"] // 24):
+            st_name, st_info, st_other, st_shndx, st_value, st_size = struct.unpack_from("<IBBHQQ", elf, sec["off"] + 24 * k)
+            if (st_info & 0xF) != 2 or st_size == 0 or st_shndx == 0 or st_shndx >= len(secs):     # STT_FUNC, defined
+                continue
+            end = elf.index(b"\0", strtab["off"] + st_name)
+            name = elf[strtab["off"] + st_name:end].decode()
+            text = secs[st_shndx]
+            o = text["off"] + (st_value - text["addr"])
+            out[name] = hashlib.sha256(elf[o:o + st_size]).hexdigest()[:16]
+    return out
+
+
 def fingerprint(so_path=DEFAULT_SO, kernel_substr="k_stream"):
-    """What a committed PMC summary is valid for: every kernel whose symbol contains kernel_substr with its resources,
-    and the hash of the device ELF."""
+    """What a committed PMC summary is valid for: every kernel whose symbol contains kernel_substr, with its resources and
+    the hash of its machine code (other kernels of the library may change without making the summary stale)."""
     tab = kernel_table(so_path)
-    ks = {n: v for n, v in sorted(tab.items()) if kernel_substr in n}
-    return {"device_elf_sha16": hashlib.sha256(device_elf(so_path)).hexdigest()[:16], "kernels": ks}
+    code = kernel_code_hashes(so_path)
+    return {"kernels": {n: dict(v, code_sha16=code.get(n)) for n, v in sorted(tab.items()) if kernel_substr in n}}
 
 
 if __name__ == "__main__":

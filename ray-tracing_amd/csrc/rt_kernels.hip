@@ -237,6 +237,14 @@ __device__ __forceinline__ void wide_decide(Q q0, Q q1, Q q2, Q q3, f3 o, f3 inv
         if (ref[2] != RT_CHILD_NONE) stack_push(sp, stk, ovf, ref[2]);
         if (ref[1] != RT_CHILD_NONE) stack_push(sp, stk, ovf, ref[1]);
     }
+#ifdef RT_EXP_EXTRA_VALU      // experiment only: N more VALU instructions per wide step (is the loaded phase VALU-bound?)
+    {
+        float dmy = Ax;
+#pragma unroll
+        for (int i = 0; i < RT_EXP_EXTRA_VALU; ++i) dmy = __builtin_fmaf(dmy, Ay, Az);
+        if (dmy == 12345.678f) ref[0] = RT_CHILD_NONE;
+    }
+#endif
     if (ref[0] != RT_CHILD_NONE) cur = ref[0];
     else cur = stack_pop(sp, stk, ovf);
 }

@@ -108,3 +108,18 @@ def test_tile_owner_is_round_robin_over_row_major_tiles():
     assert o.shape == (130, 200)
     assert o[0, 0] == 0 and o[0, 64] == 1 and o[0, 128] == 2 and o[0, 192] == 0 and o[64, 0] == 1 and o[129, 199] == 11 % 3
     assert multi_gpu.tile_owner(10, 10, 64, 1).max() == 0
+
+
+def test_bench_self_launch_starts_ranks_and_fails_loudly_without_gpus():
+    """`bench.py --gpus 2` with no launcher starts two rank processes itself (before anything touches a GPU) and hands their
+    exit status on; in this container there is no GPU, so both ranks must refuse to run -- there is no CPU fallback -- and the
+    parent must report failure instead of printing a bench line."""
+    import subprocess
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+    assert r.stderr.count("needs a GPU") == 2 and "{" not in r.stdout

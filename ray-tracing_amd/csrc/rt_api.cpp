@@ -328,7 +328,7 @@ int rt_destroy(rt_ctx *c) {
 int rt_set_stream(rt_ctx *c, void *hip_stream) {
     if (!c) return RT_ERR_ARG;
     (void)hipSetDevice(c->device);
-    HIPCHK(c, sync_all(c));
+    (void)sync_all(c);      // best effort: the stream being replaced may be one its owner has already destroyed
     c->use_null_stream = hip_stream == RT_STREAM_NULL;          // HIP's null stream, asked for explicitly
     c->ext_stream = c->use_null_stream ? nullptr : (hipStream_t)hip_stream;   // NULL: back on the sets' own streams
     select_set(c, c->cur_set);
@@ -348,10 +348,10 @@ int rt_set_frames_in_flight(rt_ctx *c, uint32_t n) {
             HIPCHK(c, hipHostMalloc((void **)&f.h_cnt, RT_CNT_N * sizeof(unsigned long long), hipHostMallocDefault));
             std::memset(f.h_cnt, 0, RT_CNT_N * sizeof(unsigned long long));
         }
-        if (c->n_px && !f.d_rgba) {
-            HIPCHK(c, hipMalloc((void **)&f.d_rgba, c->n_px * 16));
-            HIPCHK(c, hipMalloc((void **)&f.d_t, c->n_px * 4));
-            HIPCHK(c, hipMalloc((void **)&f.d_prim, c->n_px * 4));
+        if (c->n_px) {                      // each buffer on its own: an earlier call may have failed half way
+            if (!f.d_rgba) HIPCHK(c, hipMalloc((void **)&f.d_rgba, c->n_px * 16));
+            if (!f.d_t) HIPCHK(c, hipMalloc((void **)&f.d_t, c->n_px * 4));
+            if (!f.d_prim) HIPCHK(c, hipMalloc((void **)&f.d_prim, c->n_px * 4));
             f.coverage_valid = false;
         }
     }

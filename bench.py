@@ -136,12 +136,22 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pipelined", action="store_true", help="skip the extra two-frames-in-flight measurement (N=1, after the timed region)")
     ap.add_argument("--no-north-star", action="store_true", help="skip the extra 1M-triangle soup measurement (N=1, default workload, after the timed region)")
+    ap.add_argument("--in-flight", type=int, default=1, choices=[1, 2, 3, 4],
+                    help="opt-in, primary/shadow workloads: frames in flight inside the context during the timed region (rt_set_frames_in_flight); "
+                         "in tiles mode frame k's pack -> gather -> unpack then overlaps with frame k + 1's render.  The default, 1, is what `value` "
+                         "and the roofline figures are defined on (one frame at a time, unoverlapped launches)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--extra-flags", type=lambda v: int(v, 0), default=0,
                     help="experiments only: OR these RT_FLAG_* bits into every render (e.g. 0x100 = static grid, 0x200 = binary tree)")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(self_launch(args.gpus))
+
+    # stdout carries ONE JSON line and nothing else: libraries that print banners to file descriptor 1 (RCCL prints its version
+    # block there when a communicator is created) get stderr instead, the line goes to the saved descriptor at the end
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
 
     import torch
     import torch.distributed as dist
@@ -187,7 +197,11 @@ def main():
     # for the whole run so that render -> pack -> gather -> unpack are ordered without host synchronisation
     stream = torch.cuda.Stream(device=local_rank)
     torch.cuda.set_stream(stream)
-    ctx.set_stream(stream.cuda_stream)
+    overlapped = args.in_flight > 1 and len(WORKLOADS[args.workload]) <= 5 and os.environ.get("BENCH_BACKEND", "nccl") == "nccl"
+    if overlapped:      # frames in flight need the context's own streams (one per frame set); consumers order against rt_get_stream
+        ctx.set_frames_in_flight(args.in_flight)
+    else:
+        ctx.set_stream(stream.cuda_stream)
     ctx.upload_scene(scene)                   # upload + BVH build, outside the timed region
     m, p = app.camera_view()
     ctx.set_view(m, p, W, H)
@@ -221,7 +235,8 @@ def main():
         # RCCL: pack / unpack are HIP kernels on the context's stream, the packed messages torch tensors on this device.
         # gloo (one-GPU rehearsal only): gloo moves host tensors, so the frame is read back and the host restatement of
         # the same packed layout is used.
-        gather = multi_gpu.TileGather(W, H, 64, world, rank, ctx=None if gloo else ctx, device="cpu" if gloo else f"cuda:{local_rank}")
+        gather = multi_gpu.TileGather(W, H, 64, world, rank, ctx=None if gloo else ctx, device="cpu" if gloo else f"cuda:{local_rank}",
+                                      in_flight=args.in_flight if overlapped else 1)
 
     acc_t = None
     if samples:
@@ -248,10 +263,14 @@ def main():
                 rad_s.copy_(res)
         if tiles:
             # every rank sends its own tiles, packed, straight to rank 0: one xGMI link per peer, 1/N of a frame each
-            gather.combine(ctx.read_radiance() if gloo else None)
+            if overlapped:
+                gather.combine_in_flight()
+            else:
+                gather.combine(ctx.read_radiance() if gloo else None)
 
     for _ in range(args.warmup):
         step(flags)
+    ctx.synchronize()
     torch.cuda.synchronize()
     if distributed:
         dist.barrier()
@@ -259,6 +278,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step(flags | rt.FLAG_TIME_KERNELS)
+    ctx.synchronize()                          # every frame set's stream (they are the context's own with --in-flight > 1)
     torch.cuda.synchronize()
     if distributed:
         dist.barrier()
@@ -334,7 +354,7 @@ def main():
             "config": {"workload": args.workload, "resolution": f"{W}x{H}", "rays": (f"path tracing, {spp} spp, <= {segs} segments" if spp else "primary+shadow, 1 spp"),
                        "triangles": int(info.n_triangles), "bvh_nodes": int(info.n_nodes),
                        "rays_per_step_rank0": int(rays_step),
-                       "primary_hit_fraction": round(hits / max(cnt.rays_primary, 1), 4), "camera_radii": CAMERA_RADII,
+                       "primary_hit_fraction": round(hits / max(cnt.rays_primary, 1), 4), "camera_radii": CAMERA_RADII, "frames_in_flight": args.in_flight if overlapped else 1,
                        "backend": (dist.get_backend() if distributed else None), "rccl_ranks": (dist.get_world_size() if distributed and dist.get_backend() == "nccl" else None),
                        "parallelism": ("single-gpu" if not distributed else ("tiles64-roundrobin+host-pack+gather-to-rank0 (gloo rehearsal)" if gloo else "tiles64-roundrobin+hip-pack+one-gather-to-rank0+hip-unpack") if tiles else
                                        (f"sample-slices{world}+direct-reduce-scatter+gather-to-rank0" if samples else f"frames-dp{world}"))},
@@ -343,11 +363,12 @@ def main():
                          "achieved_is": "ALGORITHMIC bytes per launch / kernel time (SURVEY 8d); caches serve most of them, so it can exceed what HBM moves",
                          "hbm_frac": hbm_frac, "valu": valu, "pmc": pmc,
                          "kernel": kernel, "kernel_ms": round(kernel_ms, 4),
+                         **({"launches_overlapped": True, "note": "--in-flight > 1: launch durations overlap, achieved / frac describe shared time, not the kernel"} if overlapped else {}),
                          "algorithmic_bytes_per_launch": int(alg_bytes),
                          "node_visits": int(cnt.node_visits), "tri_tests": int(cnt.tri_tests),
                          "bytes_per_ray": round(alg_bytes / max(rays_step, 1), 1)},
         }
-        if not args.no_pipelined and not spp and world == 1:
+        if not args.no_pipelined and not spp and world == 1 and not overlapped:
             # Outside the contract's timed region and never `value`: the same frames with TWO in flight inside this one
             # context (rt_set_frames_in_flight: a second set of frame buffers and a second stream, taken in turn).  The waves
             # of one frame fill the chip while the other frame's last regions drain ("the end of the frame").
@@ -373,7 +394,7 @@ def main():
                                     "note": "ONE context, rt_set_frames_in_flight(2): two sets of frame buffers and streams taken in turn by rt_render; not the contract's value"}
             except Exception as ex:                                              # never fail the bench line for it
                 out["pipelined"] = {"error": str(ex)[:120]}
-        if not args.no_north_star and not spp and world == 1 and args.workload == "sphere_field_10k_1080p_primary_shadow":
+        if not args.no_north_star and not spp and world == 1 and not overlapped and args.workload == "sphere_field_10k_1080p_primary_shadow":
             # north_star's own target scene (1 M-triangle icosphere soup, 1080p, primary + shadow, ">= 1 Grays/s"): a
             # driver-timed figure for it, measured after the timed region like `pipelined`; never `value`
             try:
@@ -478,7 +499,8 @@ def main():
         except Exception as ex:                                                  # never fail the bench line for it
             out["roofline"]["stream_copy_GBps"] = None
             out["roofline"]["stream_copy_error"] = str(ex)[:80]
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     ctx.close()
     if distributed:
         dist.barrier()                 # rank 0's CPU baseline is done before anyone tears the group down

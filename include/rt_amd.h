@@ -68,8 +68,14 @@ int rt_set_stream(rt_ctx *ctx, void *hip_stream);
  * rt_read_*, rt_device_buffers, rt_pack_tiles and rt_get_counters refer to the frame rendered LAST (they wait for it
  * only); rt_synchronize waits for all.  Scene updates wait for every frame in flight.  Path-traced frames share one
  * accumulation buffer and are not overlapped.  On a caller's stream (rt_set_stream) all sets run on that one stream and
- * frames serialise.  Costs 24 B per pixel per extra set. */
+ * frames serialise.  Costs 24 B per pixel per extra set.  The sets' own streams are created with different stream
+ * priorities (normal, high, low, normal): one hardware-queue pool per priority is what keeps two sets off one queue,
+ * where their frames would run strictly one after the other. */
 int rt_set_frames_in_flight(rt_ctx *ctx, uint32_t n);
+/* The HIP stream (hipStream_t as void*) the frame rendered last runs on: the stream to order a consumer of
+ * rt_device_buffers / rt_pack_tiles against (hipStreamWaitEvent, or make it the current stream of a framework), e.g. a
+ * collective that sends frame k while frame k + 1 renders on the next set's stream. */
+int rt_get_stream(rt_ctx *ctx, void **hip_stream);
 
 /* ---- scene upload: replaces as_bind_group's per-frame buffer creation ---------------
  * (src/node.rs:42-50; bindings 1-4 of RayTracingInfo, src/ray_tracing.rs:84-96).

@@ -91,6 +91,8 @@ extern "C" {
     pub fn rt_set_stream(ctx: *mut rt_ctx, hip_stream: *mut c_void) -> c_int;
     /// 1..4 frames in flight inside one context (sets of frame buffers + streams taken in turn by rt_render).
     pub fn rt_set_frames_in_flight(ctx: *mut rt_ctx, n: u32) -> c_int;
+    /// The stream (hipStream_t) of the frame rendered last, to order consumers of its buffers against.
+    pub fn rt_get_stream(ctx: *mut rt_ctx, hip_stream: *mut *mut c_void) -> c_int;
     pub fn rt_upload_scene(ctx: *mut rt_ctx,
         triangles: *const rt_triangle, n_triangles: usize, meshes: *const rt_mesh_info, n_meshes: usize,
         vertices: *const rt_vertex, n_vertices: usize, materials: *const rt_material, n_materials: usize) -> c_int;

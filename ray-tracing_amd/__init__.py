@@ -77,7 +77,7 @@ class EntityView(C.Structure):
 
 
 # every symbol include/rt_amd.h and include/rt_host.h declare
-RT_SYMBOLS = ["rt_create", "rt_destroy", "rt_set_stream", "rt_set_frames_in_flight", "rt_upload_scene", "rt_upload_scene_ex", "rt_update_vertices", "rt_update_vertex_range", "rt_host_bvh_refit", "rt_set_view", "rt_render",
+RT_SYMBOLS = ["rt_create", "rt_destroy", "rt_set_stream", "rt_set_frames_in_flight", "rt_get_stream", "rt_upload_scene", "rt_upload_scene_ex", "rt_update_vertices", "rt_update_vertex_range", "rt_host_bvh_refit", "rt_set_view", "rt_render",
               "rt_synchronize", "rt_read_radiance", "rt_read_prim_ids", "rt_read_hit_t", "rt_read_bgra8_srgb",
               "rt_read_accumulation", "rt_device_buffers", "rt_resolve_accumulation", "rt_get_counters",
               "rt_encode_bgra8_srgb", "rt_tile_slot_bytes", "rt_pack_tiles", "rt_unpack_tiles", "rt_render_static",
@@ -113,7 +113,7 @@ def lib():
     L = C.CDLL(LIB_PATH)
     vp, u32, u64, sz, fp, i = C.c_void_p, C.c_uint32, C.c_uint64, C.c_size_t, C.POINTER(C.c_float), C.c_int
     sig = {
-        "rt_create": (i, [i, C.POINTER(vp)]), "rt_destroy": (i, [vp]), "rt_set_stream": (i, [vp, vp]), "rt_set_frames_in_flight": (i, [vp, u32]),
+        "rt_create": (i, [i, C.POINTER(vp)]), "rt_destroy": (i, [vp]), "rt_set_stream": (i, [vp, vp]), "rt_set_frames_in_flight": (i, [vp, u32]), "rt_get_stream": (i, [vp, C.POINTER(vp)]),
         "rt_upload_scene": (i, [vp, vp, sz, vp, sz, vp, sz, vp, sz]),
         "rt_upload_scene_ex": (i, [vp, vp, sz, vp, sz, vp, sz, vp, sz, vp, vp, sz]),
         "rt_update_vertices": (i, [vp, vp, sz, vp, sz]),
@@ -320,6 +320,12 @@ class Context:
 
     def set_stream(self, stream_ptr):
         self._chk(lib().rt_set_stream(self._h, C.c_void_p(stream_ptr)))
+
+    def get_stream(self):
+        """hipStream_t (int; 0 = the null stream) the frame rendered last runs on."""
+        p = C.c_void_p()
+        self._chk(lib().rt_get_stream(self._h, C.byref(p)))
+        return p.value or 0
 
     def set_frames_in_flight(self, n):
         self._chk(lib().rt_set_frames_in_flight(self._h, n))

@@ -293,11 +293,28 @@ int rt_create(int device_ordinal, rt_ctx **out) {
     int rc = RT_OK;
     do {
         if ((e = hipSetDevice(device_ordinal)) != hipSuccess) { rc = fail(nullptr, RT_ERR_HIP, "hipSetDevice", e); break; }
-        if ((e = hipStreamCreateWithFlags(&c->fs[0].own_stream, hipStreamNonBlocking)) != hipSuccess) { rc = fail(nullptr, RT_ERR_HIP, "hipStreamCreate", e); break; }
+        // The streams of ALL frame sets are created here.  HIP maps streams onto a few hardware queues (4 per process on
+        // this pool) and two sets whose streams share a queue never overlap (kernel trace of bench.py --in-flight 2 under
+        // RCCL: sets 0 and 1 on one queue, frames strictly serial).  Which queue a stream gets is the runtime's choice,
+        // except that each stream priority has a queue pool of its own: sets 0, 1, 2 take the normal, the high and the low
+        // priority, so the first three sets cannot share; set 3 is normal again.  Set 0 (the only one unless
+        // rt_set_frames_in_flight is called) is an ordinary stream.
+        int prio_least = 0, prio_greatest = 0;
+        if ((e = hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest)) != hipSuccess) { rc = fail(nullptr, RT_ERR_HIP, "hipDeviceGetStreamPriorityRange", e); break; }
+        const int prio[RT_MAX_IN_FLIGHT] = {0, prio_greatest, prio_least, 0};
+        for (int k = 0; k < RT_MAX_IN_FLIGHT; ++k)
+            if ((e = hipStreamCreateWithPriority(&c->fs[k].own_stream, hipStreamNonBlocking, prio[k])) != hipSuccess) break;
+        if (e != hipSuccess) { rc = fail(nullptr, RT_ERR_HIP, "hipStreamCreateWithPriority", e); break; }
         c->own_stream = c->fs[0].own_stream;
         if ((e = hipMalloc((void **)&c->fs[0].d_cnt, RT_CNT_N * sizeof(unsigned long long))) != hipSuccess) { rc = fail(nullptr, RT_ERR_HIP, "hipMalloc counters", e); break; }
         if ((e = hipHostMalloc((void **)&c->fs[0].h_cnt, RT_CNT_N * sizeof(unsigned long long), hipHostMallocDefault)) != hipSuccess) { rc = fail(nullptr, RT_ERR_HIP, "hipHostMalloc counters", e); break; }
         std::memset(c->fs[0].h_cnt, 0, RT_CNT_N * sizeof(unsigned long long));
+        // ... and each is used once right away: a stream takes its hardware queue at its first submission, which is better
+        // paid here than inside the first timed frame
+        for (FrameSet &f : c->fs)
+            if ((e = hipMemsetAsync(c->fs[0].d_cnt, 0, sizeof(unsigned long long), f.own_stream)) != hipSuccess ||
+                (e = hipStreamSynchronize(f.own_stream)) != hipSuccess) break;
+        if (e != hipSuccess) { rc = fail(nullptr, RT_ERR_HIP, "first use of the frame sets' streams", e); break; }
         select_set(c, 0);
         // the static scratch array of rt_render_static: every device holds its own copy at its own address, so the
         // address is asked for here, once per context, with this context's device current
@@ -357,6 +374,12 @@ int rt_set_frames_in_flight(rt_ctx *c, uint32_t n) {
     }
     c->n_sets = n;
     if (c->cur_set >= n) select_set(c, 0);
+    return RT_OK;
+}
+
+int rt_get_stream(rt_ctx *c, void **hip_stream) {
+    if (!c || !hip_stream) return RT_ERR_ARG;
+    *hip_stream = (void *)c->stream;          // the stream of the frame set rendered last (NULL: HIP's null stream)
     return RT_OK;
 }
 

@@ -136,16 +136,36 @@ class TileGather:
     Host path (ctx None; gloo rehearsal and CPU tests): the same layout through pack_tiles_host / unpack_tiles_host on a
     host frame the caller passes in."""
 
-    def __init__(self, width, height, tile, world, rank, ctx=None, device="cpu", rect=None, group=None):
+    def __init__(self, width, height, tile, world, rank, ctx=None, device="cpu", rect=None, group=None, in_flight=1):
         import torch
         self.world, self.rank, self.tile, self.group, self.ctx = world, rank, tile, group, ctx
         self.rect = tuple(rect) if rect is not None else (0, 0, width, height)
         self.slot = tile_slot_floats(self.rect[2], self.rect[3], tile, world)
         if ctx is not None:
             assert ctx.tile_slot_bytes(world, tile) == self.slot * 4
-        self.send = torch.zeros(self.slot, dtype=torch.float32, device=device)
-        self.recv = torch.zeros(self.slot * world, dtype=torch.float32, device=device) if rank == 0 else None
-        self.recv_list = list(self.recv.view(world, self.slot).unbind(0)) if rank == 0 else None
+        # one set of message buffers per frame in flight: frame k's gather may still be under way when frame k + 1 packs
+        self.sets = []
+        for _ in range(max(1, in_flight)):
+            send = torch.zeros(self.slot, dtype=torch.float32, device=device)
+            recv = torch.zeros(self.slot * world, dtype=torch.float32, device=device) if rank == 0 else None
+            self.sets.append((send, recv, list(recv.view(world, self.slot).unbind(0)) if rank == 0 else None))
+        self.turn = 0
+        self.send, self.recv, self.recv_list = self.sets[0]
+        self._streams = {}
+
+    def combine_in_flight(self):
+        """Device path with rt_set_frames_in_flight(n > 1) and the context on its OWN streams: pack, gather and unpack of the
+        frame rendered last are ordered on THAT frame's stream (made torch's current stream for the duration, so the
+        collective waits for the pack and the unpack for the collective), with this frame's own message buffers -- the next
+        rt_render goes to the next set's stream and overlaps with this frame's exchange."""
+        import torch
+        ptr = self.ctx.get_stream()
+        if ptr not in self._streams:
+            self._streams[ptr] = torch.cuda.ExternalStream(ptr)
+        self.send, self.recv, self.recv_list = self.sets[self.turn]
+        self.turn = (self.turn + 1) % len(self.sets)
+        with torch.cuda.stream(self._streams[ptr]):
+            return self.combine(None)
 
     def combine(self, frame=None):
         """Device path: frame is ignored (the context's radiance buffer is source and destination).  Host path: frame is

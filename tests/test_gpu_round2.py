@@ -268,6 +268,70 @@ def test_frames_in_flight_inside_one_context(n):
             ctx.set_frames_in_flight(5)
 
 
+def test_get_stream_and_tile_exchange_with_frames_in_flight():
+    """rt_get_stream names the stream of the frame rendered last, so that a consumer (the packed-tile exchange of
+    multi_gpu.TileGather.combine_in_flight) can order its work behind THAT frame while the next frame renders on the next
+    set's stream.  A second context plays the peer rank: it renders and packs its tiles, rank 0 unpacks them behind an
+    event, nothing synchronises with the host inside a burst, and the frame read at the end of each burst is the
+    unsharded frame, bit for bit."""
+    import ctypes as C
+    import torch
+    app = soup_app(200, 0x5EED0003, 640, 360)
+    app.camera_frame_scene(1.0)
+    scene = app.prepare_meshinfo()
+    cams = []
+    for k in range(6):
+        app.camera_look_at((28.0 * np.cos(k), 20.0 + 2 * k, 28.0 * np.sin(k)), (0, 0, 0), (0, 1, 0))
+        cams.append(app.camera_view())
+    with rt.Context(0) as ctx, rt.Context(0) as peer:
+        for c in (ctx, peer):
+            c.upload_scene(scene)
+        full = []
+        for m, p in cams:
+            ctx.set_view(m, p, 640, 360)
+            ctx.render(flags=rt.FLAG_SHADOW)
+            full.append(ctx.read_radiance())
+        own = ctx.get_stream()
+        assert own != 0
+        ctx.set_frames_in_flight(2)
+        seen = []
+        for _ in range(4):
+            ctx.render(flags=rt.FLAG_SHADOW)
+            seen.append(ctx.get_stream())
+        assert seen[0] != seen[1] and seen[0] == seen[2] and seen[1] == seen[3] and 0 not in seen and own in seen
+        side = torch.cuda.Stream(device=0)
+        ctx.set_stream(side.cuda_stream)
+        ctx.render(flags=rt.FLAG_SHADOW)
+        assert ctx.get_stream() == side.cuda_stream               # a caller's stream: every set renders on it
+        ctx.set_stream(C.c_void_p(-1).value)
+        ctx.render(flags=rt.FLAG_SHADOW)
+        assert ctx.get_stream() == 0                              # RT_STREAM_NULL: HIP's null stream
+        ctx.set_stream(0)
+        slot = ctx.tile_slot_bytes(2, 64)
+        msgs = [torch.zeros(slot // 4, dtype=torch.float32, device="cuda") for _ in range(2)]
+        peer_stream = torch.cuda.ExternalStream(peer.get_stream())
+        k = 0
+        for burst in (1, 2, 3):
+            for _ in range(burst):
+                m, p = cams[k % len(cams)]
+                msg = msgs[k & 1]
+                peer.set_view(m, p, 640, 360)
+                peer.render(flags=rt.FLAG_SHADOW, shard_rank=1, shard_count=2, tile_size=64)
+                peer.pack_tiles(1, 2, 64, msg.data_ptr(), slot)
+                packed = torch.cuda.Event()
+                packed.record(peer_stream)
+                ctx.set_view(m, p, 640, 360)
+                ctx.render(flags=rt.FLAG_SHADOW, shard_rank=0, shard_count=2, tile_size=64)
+                mine = torch.cuda.ExternalStream(ctx.get_stream())
+                mine.wait_event(packed)                           # what the collective does between pack and unpack
+                ctx.unpack_tiles(1, 1, 2, 64, msg.data_ptr(), slot)
+                taken = torch.cuda.Event()
+                taken.record(mine)
+                peer_stream.wait_event(taken)                     # the message buffer is free again two frames later
+                k += 1
+            assert bitwise_equal(ctx.read_radiance(), full[(k - 1) % len(cams)])
+
+
 @pytest.mark.parametrize("env", [{"RT_TUNE_POOL_DEP": "16"}, {"RT_TUNE_POOL_DEP": "24", "RT_TUNE_POOL_PICK": "8", "RT_TUNE_POOL_DRAIN": "1"},
                                  {"RT_TUNE_PATH_SPLIT": "1", "RT_TUNE_PATH_REFILL_MIN": "16"}, {"RT_TUNE_PATH_SPLIT": "1", "RT_TUNE_PATH_REFILL_MIN": "1"}])
 def test_measured_opt_in_variants_stay_bit_identical(env, monkeypatch):

@@ -287,6 +287,8 @@ int rt_create(int device_ordinal, rt_ctx **out) {
         c->tune.pool_drain = env("RT_TUNE_POOL_DRAIN", 0, 0, 1);
         c->tune.path_split = env("RT_TUNE_PATH_SPLIT", 0, 0, 1);
         c->tune.path_refill_min = env("RT_TUNE_PATH_REFILL_MIN", 16, 1, 64);
+        c->tune.path_sort = env("RT_TUNE_PATH_SORT", 0, 0, 6);
+        c->tune.path_sort_key = env("RT_TUNE_PATH_SORT_KEY", 0, 0, 1);
         c->tune_wide = env("RT_TUNE_WIDE", 1, 0, 1);
         c->tune_sample_batch = env("RT_TUNE_SAMPLE_BATCH", 16, 1, 16);
     }

@@ -1263,6 +1263,97 @@ __global__ __launch_bounds__(RT_BLOCK, RT_MIN_WAVES) void k_path_bounce(RtSceneD
     }
 }
 
+// ---- bounce segments with the queue regrouped by ray direction (round 2) ------------------------------
+// A block takes sort_m x 256 consecutive queued paths (screen neighbours: the queue is in compaction order), counting-sorts
+// their indices in LDS by a direction key -- sign octant (8 bins) or octant x major axis (24 bins) -- and then walks them
+// 256 at a time in that order, so the 64 rays of a wave start from nearby points AND head the same way.  No extra pass over
+// the queue, no global atomics: the directions are read twice (the second time from the cache), the permutation lives in
+// LDS.  A path's arithmetic is unchanged; only which lanes share a wave changes, so the sums are bit-identical.
+#define RT_SORT_MAX_M 6u            // 2 x 6 x 256 x 2 B of LDS beside the stacks: still 7 blocks per CU
+#define RT_SORT_BINS 32u
+__device__ __forceinline__ uint32_t path_sort_key(float dx, float dy, float dz, uint32_t mode) {
+    const uint32_t oct = (dx < 0.0f ? 1u : 0u) | (dy < 0.0f ? 2u : 0u) | (dz < 0.0f ? 4u : 0u);
+    if (mode == 0u) return oct;
+    const float ax = fabsf(dx), ay = fabsf(dy), az = fabsf(dz);
+    const uint32_t major = (ax >= ay && ax >= az) ? 0u : (ay >= az ? 1u : 2u);
+    return oct * 3u + major;
+}
+template <bool COUNT>
+__global__ __launch_bounds__(RT_BLOCK, RT_MIN_WAVES) void k_path_bounce_sorted(RtSceneDev S, uint32_t flags, int is_last,
+                                                          float4 *__restrict__ contrib, uint32_t n_px, RtPathQueue qi, RtPathQueue qo,
+                                                          unsigned long long *__restrict__ counters, int qi_ctr,
+                                                          int qo_ctr, uint32_t sort_m, uint32_t sort_key) {
+    __shared__ int s_stack[RT_STACK_LDS * RT_BLOCK];
+    __shared__ uint16_t s_tmp[RT_SORT_MAX_M * RT_BLOCK];     // key << 11 | arrival rank within the key's bin (< 1536)
+    __shared__ uint16_t s_perm[RT_SORT_MAX_M * RT_BLOCK];    // sorted position -> index within the chunk
+    __shared__ uint32_t s_bin[64];
+    int *stk = s_stack + threadIdx.x;
+    const uint32_t n = (uint32_t)counters[qi_ctr];
+    const uint32_t chunk = RT_BLOCK * sort_m;
+    Cnt c; c.nodes = 0; c.tris = 0; c.meshes = 0; c.wnodes = 0; c.wtris = 0; c.walive = 0;
+    uint32_t n_bounce = 0;
+    for (uint32_t base = blockIdx.x * chunk; base < n; base += gridDim.x * chunk) {   // the trip count is the same for a whole block
+        const uint32_t cnt = n - base < chunk ? n - base : chunk;
+        if (threadIdx.x < 64u) s_bin[threadIdx.x] = 0u;
+        __syncthreads();
+        for (uint32_t j = threadIdx.x; j < cnt; j += RT_BLOCK) {
+            const uint32_t i = base + j;
+            const uint32_t key = path_sort_key(qi.dx[i], qi.dy[i], qi.dz[i], sort_key);
+            s_tmp[j] = (uint16_t)((key << 11) | atomicAdd(&s_bin[key], 1u));
+        }
+        __syncthreads();
+        if (threadIdx.x < 64u) {                             // exclusive prefix over the bins, one wave
+            const uint32_t v = s_bin[threadIdx.x];
+            uint32_t incl = v;
+            for (int ofs = 1; ofs < 64; ofs <<= 1) {
+                const uint32_t up = __shfl_up(incl, ofs);
+                if ((int)threadIdx.x >= ofs) incl += up;
+            }
+            s_bin[threadIdx.x] = incl - v;
+        }
+        __syncthreads();
+        for (uint32_t j = threadIdx.x; j < cnt; j += RT_BLOCK) {
+            const uint32_t e = s_tmp[j];
+            s_perm[s_bin[e >> 11] + (e & 0x7FFu)] = (uint16_t)j;
+        }
+        __syncthreads();
+        for (uint32_t j0 = 0; j0 < cnt; j0 += RT_BLOCK) {    // uniform per block: queue_slot's ballots see whole waves
+            const uint32_t j = j0 + threadIdx.x;
+            const bool active = j < cnt;
+            bool alive = false;
+            f3 o, d, col; uint32_t rng = 0, pixel = 0;
+            if (active) {
+                const uint32_t i = base + s_perm[j];
+                o = F3(qi.ox[i], qi.oy[i], qi.oz[i]);
+                d = F3(qi.dx[i], qi.dy[i], qi.dz[i]);
+                Hit h;
+                trace<false, COUNT>(S, o, d, flags, stk, h, c);
+                const uint32_t i2 = base + s_perm[j];        // re-read after the traversal (registers)
+                col = F3(qi.cr[i2], qi.cg[i2], qi.cb[i2]);
+                rng = qi.rng[i2]; pixel = qi.pixel[i2];
+                alive = path_scatter(S, h, o, d, col, rng, contrib + (size_t)(pixel >> RT_PATH_SLOT_SHIFT) * n_px + (pixel & RT_PATH_PIXEL_MASK)) && !is_last;
+                ++n_bounce;
+            }
+            uint32_t slot = queue_slot(counters + qo_ctr, alive);
+            if (alive) {
+                qo.ox[slot] = o.x; qo.oy[slot] = o.y; qo.oz[slot] = o.z;
+                qo.dx[slot] = d.x; qo.dy[slot] = d.y; qo.dz[slot] = d.z;
+                qo.cr[slot] = col.x; qo.cg[slot] = col.y; qo.cb[slot] = col.z;
+                qo.rng[slot] = rng; qo.pixel[slot] = pixel;
+            }
+        }
+    }
+    wave_sum(counters + RT_CNT_BOUNCE, n_bounce);
+    if (COUNT) {
+        wave_sum(counters + RT_CNT_NODES, c.nodes);
+        wave_sum(counters + RT_CNT_TRIS, c.tris);
+        wave_sum(counters + RT_CNT_MESH, c.meshes);
+        wave_sum(counters + RT_CNT_WNODE, c.wnodes);
+        wave_sum(counters + RT_CNT_WTRI, c.wtris);
+        wave_sum(counters + RT_CNT_WALIVE, c.walive);
+    }
+}
+
 // ---- bounce segments, split (round 2): k_path_trace walks, k_path_shade scatters -------------------------------------
 // k_path_bounce keeps a wave on its 64 paths until the LONGEST of their segments has ended (its VALU instructions run
 // with 36 % of the lanes; profiles/r2/pmc_path_*.txt), and every attempt to refill lanes inside it also ran the scatter
@@ -1781,6 +1872,16 @@ hipError_t rtk_launch_path_bounce(hipStream_t st, const RtSceneDev &S, uint32_t 
     if (nb == 0) return hipSuccess;
     uint32_t persist = (flags & (RT_FLAG_STATIC_GRID | RT_FLAG_BRUTE_FORCE)) ? 0u : 1u;
     uint32_t grid = persist && tune.persist_blocks < nb ? tune.persist_blocks : nb;
+    if (tune.path_sort && persist) {        // opt-in: the queue regrouped by direction inside the kernel
+        const uint32_t m = tune.path_sort < RT_SORT_MAX_M ? tune.path_sort : RT_SORT_MAX_M;
+        const uint32_t nc = (capacity + RT_BLOCK * m - 1) / (RT_BLOCK * m);
+        const uint32_t g = tune.persist_blocks < nc ? tune.persist_blocks : nc;
+        if (flags & RT_FLAG_COUNTERS)
+            hipLaunchKernelGGL(k_path_bounce_sorted<true>, dim3(g), dim3(RT_BLOCK), 0, st, S, flags, is_last, (float4 *)contrib, n_px, qin, qout, counters, qin_counter, qout_counter, m, tune.path_sort_key);
+        else
+            hipLaunchKernelGGL(k_path_bounce_sorted<false>, dim3(g), dim3(RT_BLOCK), 0, st, S, flags, is_last, (float4 *)contrib, n_px, qin, qout, counters, qin_counter, qout_counter, m, tune.path_sort_key);
+        return hipGetLastError();
+    }
     if (flags & RT_FLAG_COUNTERS)
         hipLaunchKernelGGL(k_path_bounce<true>, dim3(grid), dim3(RT_BLOCK), 0, st, S, flags, is_last, (float4 *)contrib, n_px, qin, qout, counters, qin_counter, qout_counter, persist);
     else

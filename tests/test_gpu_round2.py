@@ -333,11 +333,13 @@ def test_get_stream_and_tile_exchange_with_frames_in_flight():
 
 
 @pytest.mark.parametrize("env", [{"RT_TUNE_POOL_DEP": "16"}, {"RT_TUNE_POOL_DEP": "24", "RT_TUNE_POOL_PICK": "8", "RT_TUNE_POOL_DRAIN": "1"},
-                                 {"RT_TUNE_PATH_SPLIT": "1", "RT_TUNE_PATH_REFILL_MIN": "16"}, {"RT_TUNE_PATH_SPLIT": "1", "RT_TUNE_PATH_REFILL_MIN": "1"}])
+                                 {"RT_TUNE_PATH_SPLIT": "1", "RT_TUNE_PATH_REFILL_MIN": "16"}, {"RT_TUNE_PATH_SPLIT": "1", "RT_TUNE_PATH_REFILL_MIN": "1"},
+                                 {"RT_TUNE_PATH_SORT": "1"}, {"RT_TUNE_PATH_SORT": "6", "RT_TUNE_PATH_SORT_KEY": "1"}])
 def test_measured_opt_in_variants_stay_bit_identical(env, monkeypatch):
-    """Round 2 measured two re-packing schemes and kept neither as the default: the block tail pool of
-    k_stream (RT_TUNE_POOL_DEP) and bounce segments split into a lane-refilled traversal kernel + a scatter kernel
-    (RT_TUNE_PATH_SPLIT).  They stay in the library for A/B runs, so they stay correct: same frames, same counted visits."""
+    """Round 2 measured three re-packing schemes and kept none as the default: the block tail pool of
+    k_stream (RT_TUNE_POOL_DEP), bounce segments split into a lane-refilled traversal kernel + a scatter kernel
+    (RT_TUNE_PATH_SPLIT), and the bounce queue regrouped by ray direction inside the bounce kernel (RT_TUNE_PATH_SORT).
+    They stay in the library for A/B runs, so they stay correct: same frames, same counted visits."""
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     app = soup_app(300, 0x5EED0003, 640, 360)

@@ -67,8 +67,9 @@ int rt_set_stream(rt_ctx *ctx, void *hip_stream);
  * (src/node.rs:29-79) submits one frame after the other the same way and lets the GPU queue overlap them.
  * rt_read_*, rt_device_buffers, rt_pack_tiles and rt_get_counters refer to the frame rendered LAST (they wait for it
  * only); rt_synchronize waits for all.  Scene updates wait for every frame in flight.  Path-traced frames share one
- * accumulation buffer and are not overlapped.  On a caller's stream (rt_set_stream) all sets run on that one stream and
- * frames serialise.  Costs 24 B per pixel per extra set.  The sets' own streams are created with different stream
+ * accumulation buffer and are not overlapped; rt_read_accumulation and rt_resolve_accumulation wait for them too.
+ * On a caller's stream (rt_set_stream) all sets run on that one stream and frames serialise.  Costs 24 B per pixel
+ * per extra set.  The sets' own streams are created with different stream
  * priorities (normal, high, low, normal): one hardware-queue pool per priority is what keeps two sets off one queue,
  * where their frames would run strictly one after the other. */
 int rt_set_frames_in_flight(rt_ctx *ctx, uint32_t n);

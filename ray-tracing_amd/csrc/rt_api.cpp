@@ -145,6 +145,12 @@ hipError_t sync_all(rt_ctx *c) {
     }
     return first;
 }
+// The accumulation buffer belongs to the path-traced frames, which all run on set 0 (rt_render): a reader that arrives
+// after a later primary frame on another set has to wait for set 0's stream, not only for the frame rendered last.
+hipError_t wait_path_frames(rt_ctx *c) {
+    if (c->n_sets > 1 && c->cur_set != 0) return hipStreamSynchronize(set_stream_of(c, 0));
+    return hipSuccess;
+}
 void invalidate_coverage(rt_ctx *c) { for (FrameSet &f : c->fs) f.coverage_valid = false; }
 
 void free_scene(rt_ctx *c) {
@@ -1173,6 +1179,7 @@ int rt_get_counters(rt_ctx *c, rt_counters *out) {
     if (!c || !out) return RT_ERR_ARG;
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->ev_used && c->n_sets > 1) HIPCHK(c, sync_all(c));     // timed frames of other sets: their events must have completed
     double ms = 0.0;
     for (size_t i = 0; i + 1 < c->ev_used; i += 2) {
         float t = 0.0f;
@@ -1210,6 +1217,7 @@ int rt_read_radiance(rt_ctx *c, float *rgba, size_t n_floats) {
     return read_back(c, rgba, c ? c->d_rgba : nullptr, c ? c->n_px * 16 : 0, n_floats * 4, "rt_read_radiance: size must be W*H*4 floats");
 }
 int rt_read_accumulation(rt_ctx *c, float *accum, size_t n_floats) {
+    if (c && c->has_view) { HIPCHK(c, hipSetDevice(c->device)); HIPCHK(c, wait_path_frames(c)); }
     return read_back(c, accum, c ? c->d_accum : nullptr, c ? c->n_px * 16 : 0, n_floats * 4, "rt_read_accumulation: size must be W*H*4 floats");
 }
 int rt_read_prim_ids(rt_ctx *c, uint32_t *prim, size_t n) {
@@ -1257,6 +1265,7 @@ int rt_resolve_accumulation(rt_ctx *c, uint32_t total_samples) {
     if (!c || total_samples == 0) return RT_ERR_ARG;
     if (!c->has_view) return RT_NOT_READY;
     HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, wait_path_frames(c));
     HIPCHK(c, rtk_launch_resolve(c->stream, c->d_accum, c->d_rgba, c->n_px, 0.0f, total_samples));
     return RT_OK;
 }

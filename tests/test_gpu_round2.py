@@ -247,9 +247,15 @@ def test_frames_in_flight_inside_one_context(n):
         ctx.render(flags=rt.FLAG_PATH_TRACE, spp=3, max_segments=4, seed=4)
         ctx.render(flags=rt.FLAG_SHADOW)
         ctx.render(flags=rt.FLAG_PATH_TRACE | rt.FLAG_ACCUMULATE, spp=2, sample_first=3, max_segments=4, seed=4)
+        ctx.render(flags=rt.FLAG_SHADOW)           # the frame rendered last is on another set: the sums' reader still waits for set 0
         acc = ctx.read_accumulation()
         acc_o, _ = orc.render_path(oracle_scene(scene), orc.make_view(m, p, 640, 360), 5, 4, seed=4, threads=16)
         assert bitwise_equal(acc, acc_o)
+        # timed frames on every set, counters asked for without a synchronize in between: all event pairs are complete
+        for _ in range(n + 1):
+            ctx.render(flags=rt.FLAG_SHADOW | rt.FLAG_TIME_KERNELS)
+        c = ctx.counters()
+        assert c.kernel_launches == n + 1 and c.kernel_ms > 0.0
         # a vertex update while frames are in flight: the next frame sees the moved scene, the one before it did not
         v2 = scene.vertices.copy()
         v2["pos"][:, 1] += np.float32(0.75)

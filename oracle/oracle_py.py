@@ -107,6 +107,10 @@ def lib():
                                        C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_int,
                                        C.POINTER(OWalkCounts)]
     L.orc_render_path_tree.restype = C.c_uint64
+    L.orc_render_path_tree_crop.argtypes = [C.POINTER(OScene), C.POINTER(OTree), C.POINTER(OView), C.c_uint32, C.c_uint32,
+                                            C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32), C.c_void_p,
+                                            C.c_int, C.POINTER(OWalkCounts)]
+    L.orc_render_path_tree_crop.restype = C.c_uint64
     L.orc_resolve.argtypes = [C.c_void_p, C.c_size_t, C.c_uint32, C.c_void_p]
     L.orc_encode_bgra8_srgb.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p]
     L.orc_prepare_meshinfo.argtypes = [C.POINTER(OEntity), C.c_size_t, C.c_void_p, C.POINTER(C.c_size_t),
@@ -267,6 +271,21 @@ def render_path_tree(scene, tree, view, spp, max_segments=4, seed=0, stream=0, s
     segs = lib().orc_render_path_tree(C.byref(scene.c), C.byref(tree.c), C.byref(view), flags, spp, sample_first,
                                       max_segments, seed, stream, accum.ctypes.data, threads, C.byref(c))
     return accum, int(segs), (int(c.node_visits), int(c.tri_tests), int(c.mesh_culls))
+
+
+def render_path_tree_crop(scene, tree, view, crop, spp, max_segments=4, seed=0, stream=0, sample_first=0, flags=0, threads=8):
+    """The running sums of render_path_tree for the pixels of crop = (x, y, w, h) only, returned as an (h, w, 4) array:
+    a pixel's value does not depend on the crop (whole frames at 4K x 64 samples or 8K take the host minutes)."""
+    x, y, w, h = crop
+    H, W = view.height, view.width
+    assert x + w <= W and y + h <= H
+    # the C side indexes the whole target: give it a buffer whose rows y .. y + h - 1 exist and point it h rows up
+    rows = np.zeros((h, W, 4), np.float32)
+    base = rows.ctypes.data - y * W * 16
+    c = OWalkCounts()
+    lib().orc_render_path_tree_crop(C.byref(scene.c), C.byref(tree.c), C.byref(view), flags, spp, sample_first, max_segments,
+                                    seed, stream, (C.c_uint32 * 4)(x, y, w, h), base, threads, C.byref(c))
+    return rows[:, x:x + w].copy()
 
 
 def resolve(accum, total_samples):

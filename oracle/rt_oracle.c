@@ -343,6 +343,7 @@ typedef struct {
     uint64_t rays;
     /* path */
     uint32_t spp, sample_first, max_segments, seed, stream; float *accum;
+    uint32_t crop[4];   /* path: only pixels of this rectangle of the target (x, y, w, h; w == 0: no crop) */
     /* tree walk (NULL: the reference-shaped loop) */
     const orc_tree *tr; orc_walk_counts cnt;
 } job_t;
@@ -525,6 +526,14 @@ static void *path_worker(void *arg) {
     uint32_t W = j->v->width;
     uint32_t x0, y0, vw, vh;
     view_rect(j->v, &x0, &y0, &vw, &vh);
+    if (j->crop[2]) {   /* the covered rectangle, cut down to the crop: the same pixels get the same values, fewer of them */
+        uint32_t cx0 = j->crop[0] > x0 ? j->crop[0] : x0, cy0 = j->crop[1] > y0 ? j->crop[1] : y0;
+        uint64_t cx1 = (uint64_t)j->crop[0] + j->crop[2], cy1 = (uint64_t)j->crop[1] + j->crop[3];
+        if (cx1 > (uint64_t)x0 + vw) cx1 = (uint64_t)x0 + vw;
+        if (cy1 > (uint64_t)y0 + vh) cy1 = (uint64_t)y0 + vh;
+        vw = cx1 > cx0 ? (uint32_t)(cx1 - cx0) : 0; vh = cy1 > cy0 ? (uint32_t)(cy1 - cy0) : 0;
+        x0 = cx0; y0 = cy0;
+    }
     j->rays = 0;
     memset(&j->cnt, 0, sizeof j->cnt);
     for (uint32_t row = (uint32_t)j->tid; row < vh; row += (uint32_t)j->nth) {
@@ -574,6 +583,17 @@ uint64_t orc_render_path_tree(const orc_scene *s, const orc_tree *tr, const orc_
     job_t j; memset(&j, 0, sizeof j);
     j.s = s; j.v = v; j.flags = flags; j.spp = spp; j.sample_first = sample_first;
     j.max_segments = max_segments; j.seed = seed; j.stream = stream; j.accum = accum; j.tr = tr;
+    uint64_t rays = run_jobs(&j, n_threads, path_worker);
+    if (cnt) *cnt = j.cnt;
+    return rays;
+}
+uint64_t orc_render_path_tree_crop(const orc_scene *s, const orc_tree *tr, const orc_view *v, uint32_t flags,
+                                   uint32_t spp, uint32_t sample_first, uint32_t max_segments,
+                                   uint32_t seed, uint32_t stream, const uint32_t crop[4], float *accum, int n_threads, orc_walk_counts *cnt) {
+    job_t j; memset(&j, 0, sizeof j);
+    j.s = s; j.v = v; j.flags = flags; j.spp = spp; j.sample_first = sample_first;
+    j.max_segments = max_segments; j.seed = seed; j.stream = stream; j.accum = accum; j.tr = tr;
+    if (crop) memcpy(j.crop, crop, sizeof j.crop);
     uint64_t rays = run_jobs(&j, n_threads, path_worker);
     if (cnt) *cnt = j.cnt;
     return rays;

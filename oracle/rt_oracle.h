@@ -160,6 +160,13 @@ uint64_t orc_render_path(const orc_scene *s, const orc_view *v, uint32_t flags,
 uint64_t orc_render_path_tree(const orc_scene *s, const orc_tree *tr, const orc_view *v, uint32_t flags,
                               uint32_t spp, uint32_t sample_first, uint32_t max_segments,
                               uint32_t seed, uint32_t stream, float *accum, int n_threads, orc_walk_counts *cnt);
+/* the same for the pixels of one rectangle of the target only (crop = x, y, w, h; NULL: all): every pixel gets the
+ * value it has in the whole frame (seeds and rays depend on the pixel, not on the crop), so a few crops check a frame
+ * whose whole would take the host minutes.  Test infrastructure of the full-size configs[3] / configs[4] cases. */
+uint64_t orc_render_path_tree_crop(const orc_scene *s, const orc_tree *tr, const orc_view *v, uint32_t flags,
+                                   uint32_t spp, uint32_t sample_first, uint32_t max_segments,
+                                   uint32_t seed, uint32_t stream, const uint32_t crop[4], float *accum, int n_threads,
+                                   orc_walk_counts *cnt);
 /* out = accum / total_samples (alpha too). */
 void orc_resolve(const float *accum, size_t n_px, uint32_t total_samples, float *rgba);
 

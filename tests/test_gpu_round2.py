@@ -411,3 +411,71 @@ def test_config4_sample_slices_sum_to_the_unsliced_frame():
             total2 = total2 + ctx.read_accumulation()
         d = (total2.astype(np.float64) - full.astype(np.float64)) / 8.0
         assert float(np.sqrt(np.mean(d * d))) <= 1e-3 and np.all(total2[..., 3] == 8.0)
+
+
+def _oracle_rects(osc, tree, app, W, H, rects, **kw):
+    """The oracle's running sums on a few rectangles of the W x H frame (orc_render_path_tree_crop: a pixel's value does
+    not depend on the crop)."""
+    m, p = app.camera_view()
+    view = orc.make_view(m, p, W, H)
+    return [orc.render_path_tree_crop(osc, tree, view, r, threads=16, **kw) for r in rects]
+
+
+def test_config3_full_size_64spp_eight_way_tile_shard():
+    """configs[3] at its own numbers: 3840x2160, 64 samples per pixel, <= 4 segments, 64x64 tiles dealt to EIGHT ranks.  One
+    GPU plays the eight ranks in turn: each renders its tiles with all 64 samples and packs its radiance tiles
+    (rt_pack_tiles), rank 0 scatters the seven peers' messages into its frame (rt_unpack_tiles) -- the data path of
+    bench.py --gpus 8 minus the wire.  The combined frame is the unsharded 64-sample frame bit for bit, and that frame's
+    running sums are the oracle's on three viewports (the whole frame at 64 samples is minutes of host time)."""
+    import torch
+    W, H, SPP, SEGS, RANKS = 3840, 2160, 64, 4, 8
+    app = soup_app(1389, 0x5EED0003, W, H)
+    app.camera_frame_scene(1.0)
+    scene = app.prepare_meshinfo()
+    with rt.Context(0) as ctx:
+        ctx.upload_scene(scene)
+        m, p = app.camera_view()
+        ctx.set_view(m, p, W, H)
+        assert ctx.render(flags=rt.FLAG_PATH_TRACE, spp=SPP, max_segments=SEGS, seed=11) == rt.RT_OK
+        full_acc = ctx.read_accumulation()
+        full = ctx.read_radiance()
+        assert np.all(full_acc[..., 3] == float(SPP))
+        tree = orc.Tree(*ctx.read_bvh(), ctx.read_bvh_wide())
+        rects = [(0, 0, 96, 64), (1900, 1050, 128, 48), (W - 80, H - 56, 80, 56)]
+        for (x, y, w, h), want in zip(rects, _oracle_rects(oracle_scene(scene), tree, app, W, H, rects, spp=SPP, max_segments=SEGS, seed=11)):
+            assert bitwise_equal(full_acc[y:y + h, x:x + w], want)
+        slot = ctx.tile_slot_bytes(RANKS, 64)
+        recv = torch.zeros(RANKS * slot // 4, dtype=torch.float32, device="cuda")
+        for rank in range(RANKS - 1, -1, -1):              # rank 0 last: its frame is the one the peers' tiles go into
+            assert ctx.render(flags=rt.FLAG_PATH_TRACE, spp=SPP, max_segments=SEGS, seed=11, stream_id=0,
+                              shard_rank=rank, shard_count=RANKS, tile_size=64) == rt.RT_OK
+            if rank:
+                ctx.pack_tiles(rank, RANKS, 64, recv.data_ptr() + rank * slot, slot)
+        ctx.unpack_tiles(1, RANKS - 1, RANKS, 64, recv.data_ptr() + slot, slot)
+        assert bitwise_equal(ctx.read_radiance(), full)
+
+
+def test_config4_full_size_8k_sample_slices():
+    """configs[4] at its own size: 7680x4320, the 10 M-triangle scene, <= 8 segments, sample-sliced over EIGHT ranks (one
+    sample each, one RNG stream).  One GPU plays the eight ranks in turn; their running sums, added in rank order as
+    SampleReduce adds them, are the 8-sample frame of one context bit for bit, and that frame's sums are the oracle's on
+    three viewports."""
+    W, H, SEGS, RANKS = 7680, 4320, 8, 8
+    app = soup_app(13889, 0x5EED0005, W, H)
+    app.camera_frame_scene(1.0)
+    scene = app.prepare_meshinfo()
+    with rt.Context(0) as ctx:
+        ctx.upload_scene(scene)
+        m, p = app.camera_view()
+        ctx.set_view(m, p, W, H)
+        assert ctx.render(flags=rt.FLAG_PATH_TRACE, spp=RANKS, max_segments=SEGS, seed=6) == rt.RT_OK
+        full = ctx.read_accumulation()
+        tree = orc.Tree(*ctx.read_bvh(), ctx.read_bvh_wide())
+        rects = [(0, 0, 64, 48), (3800, 2100, 96, 64), (W - 64, H - 40, 64, 40)]
+        for (x, y, w, h), want in zip(rects, _oracle_rects(oracle_scene(scene), tree, app, W, H, rects, spp=RANKS, max_segments=SEGS, seed=6)):
+            assert bitwise_equal(full[y:y + h, x:x + w], want)
+        total = np.zeros_like(full)
+        for r in range(RANKS):
+            assert ctx.render(flags=rt.FLAG_PATH_TRACE, spp=1, sample_first=r, max_segments=SEGS, seed=6, stream_id=0) == rt.RT_OK
+            total += ctx.read_accumulation()                # rank order
+        assert bitwise_equal(total, full)

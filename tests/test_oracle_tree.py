@@ -118,3 +118,20 @@ def test_path_tracing_through_the_tree_equals_the_reference_shaped_loop():
     for tree in _trees(scene):
         acc, segs, cnt = orc.render_path_tree(osc, tree, view, spp=3, max_segments=4, seed=7, stream=1, threads=4)
         assert segs == segs_o and (_bits(acc) == _bits(acc_o)).all() and cnt[0] > 0
+
+
+def test_cropped_path_frames_hold_the_whole_frames_values():
+    """orc_render_path_tree_crop (what the full-size configs[3] / configs[4] GPU tests check against): the pixels of a
+    rectangle get exactly the values they have in the whole frame, with and without a viewport, at the frame's edges too."""
+    app = soup_app(12, 0x5EED0003, 64, 48, subdivisions=2)
+    scene = app.prepare_meshinfo()
+    osc = oracle_scene(scene)
+    _, wide = _trees(scene)
+    m, p = app.camera_view()
+    for viewport in (None, (5, 7, 50, 30)):
+        view = orc.make_view(m, p, 64, 48, viewport=viewport)
+        whole, _, _ = orc.render_path_tree(osc, wide, view, spp=3, max_segments=4, seed=7, sample_first=2, threads=4)
+        for crop in ((0, 0, 64, 48), (0, 0, 9, 5), (20, 11, 17, 23), (64 - 6, 48 - 4, 6, 4), (3, 40, 61, 8)):
+            x, y, w, h = crop
+            part = orc.render_path_tree_crop(osc, wide, view, crop, spp=3, max_segments=4, seed=7, sample_first=2, threads=3)
+            assert part.shape == (h, w, 4) and (_bits(part) == _bits(whole[y:y + h, x:x + w])).all()

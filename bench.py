@@ -136,10 +136,11 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pipelined", action="store_true", help="skip the extra two-frames-in-flight measurement (N=1, after the timed region)")
     ap.add_argument("--no-north-star", action="store_true", help="skip the extra 1M-triangle soup measurement (N=1, default workload, after the timed region)")
-    ap.add_argument("--in-flight", type=int, default=1, choices=[1, 2, 3, 4],
-                    help="opt-in, primary/shadow workloads: frames in flight inside the context during the timed region (rt_set_frames_in_flight); "
-                         "in tiles mode frame k's pack -> gather -> unpack then overlaps with frame k + 1's render.  The default, 1, is what `value` "
-                         "and the roofline figures are defined on (one frame at a time, unoverlapped launches)")
+    ap.add_argument("--in-flight", type=int, default=4, choices=[1, 2, 3, 4],
+                    help="primary/shadow workloads: frames in flight inside the context during the timed region (rt_set_frames_in_flight: "
+                         "the render node submits frame after frame without waiting, as the reference's does; in tiles mode frame k's "
+                         "pack -> gather -> unpack overlaps with the next frames' renders).  The same at every N.  1: one frame at a time "
+                         "(always measured too, after the timed region: one_frame_at_a_time, and the roofline's launch duration)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--extra-flags", type=lambda v: int(v, 0), default=0,
                     help="experiments only: OR these RT_FLAG_* bits into every render (e.g. 0x100 = static grid, 0x200 = binary tree)")
@@ -197,11 +198,25 @@ def main():
     # for the whole run so that render -> pack -> gather -> unpack are ordered without host synchronisation
     stream = torch.cuda.Stream(device=local_rank)
     torch.cuda.set_stream(stream)
-    overlapped = args.in_flight > 1 and len(WORKLOADS[args.workload]) <= 5 and os.environ.get("BENCH_BACKEND", "nccl") == "nccl"
-    if overlapped:      # frames in flight need the context's own streams (one per frame set); consumers order against rt_get_stream
-        ctx.set_frames_in_flight(args.in_flight)
-    else:
-        ctx.set_stream(stream.cuda_stream)
+    gloo_rehearsal = distributed and os.environ.get("BENCH_BACKEND", "nccl") != "nccl"
+
+    def frames_in_flight():
+        """Path-traced frames share one accumulation buffer and never overlap; the gloo rehearsal stages through the host."""
+        if len(WORKLOADS[args.workload]) > 5 or gloo_rehearsal:
+            return 1
+        return args.in_flight
+    n_in_flight = frames_in_flight()
+    overlapped = n_in_flight > 1
+
+    def configure(n):
+        """n > 1: the context's own streams, one per frame set (consumers order against rt_get_stream).  1: torch's side stream."""
+        if n > 1:
+            ctx.set_stream(0)
+            ctx.set_frames_in_flight(n)
+        else:
+            ctx.set_frames_in_flight(1)
+            ctx.set_stream(stream.cuda_stream)
+    configure(n_in_flight)
     ctx.upload_scene(scene)                   # upload + BVH build, outside the timed region
     m, p = app.camera_view()
     ctx.set_view(m, p, W, H)
@@ -236,7 +251,7 @@ def main():
         # gloo (one-GPU rehearsal only): gloo moves host tensors, so the frame is read back and the host restatement of
         # the same packed layout is used.
         gather = multi_gpu.TileGather(W, H, 64, world, rank, ctx=None if gloo else ctx, device="cpu" if gloo else f"cuda:{local_rank}",
-                                      in_flight=args.in_flight if overlapped else 1)
+                                      in_flight=n_in_flight)
 
     acc_t = None
     if samples:
@@ -262,36 +277,49 @@ def main():
             if rank == 0:
                 rad_s.copy_(res)
         if tiles:
-            # every rank sends its own tiles, packed, straight to rank 0: one xGMI link per peer, 1/N of a frame each
-            if overlapped:
-                gather.combine_in_flight()
+            # every rank sends its own tiles, packed, straight to rank 0: one xGMI link per peer, 1/N of a frame each;
+            # ordered on the stream of the frame just rendered, so the next frame's render overlaps with it
+            if gloo:
+                gather.combine(ctx.read_radiance())
             else:
-                gather.combine(ctx.read_radiance() if gloo else None)
+                gather.combine_in_flight()
 
-    for _ in range(args.warmup):
-        step(flags)
-    ctx.synchronize()
-    torch.cuda.synchronize()
-    if distributed:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step(flags | rt.FLAG_TIME_KERNELS)
-    ctx.synchronize()                          # every frame set's stream (they are the context's own with --in-flight > 1)
-    torch.cuda.synchronize()
-    if distributed:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    kc = ctx.counters()                        # sums the per-launch HIP event pairs
-    kernel_ms = kc.kernel_ms / (args.steps if spp else max(kc.kernel_launches, 1))   # per launch; per frame when path tracing
+    def quiesce():
+        ctx.synchronize()                          # every frame set's stream
+        torch.cuda.synchronize()
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def timed(n_frames, steps, warmup):
+        """steps frames with n_frames in flight, bracketed by barrier + synchronize; (seconds, max over ranks; kernel ms per launch)."""
+        configure(n_frames)
+        for _ in range(warmup):
+            step(flags)
+        quiesce()
+        ctx.counters()                             # start the HIP-event sums afresh
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step(flags | rt.FLAG_TIME_KERNELS)
+        quiesce()
+        dt_ = time.perf_counter() - t0
+        kc = ctx.counters()                        # sums the per-launch HIP event pairs
+        k_ms = kc.kernel_ms / (steps if spp else max(kc.kernel_launches, 1))   # per launch; per frame when path tracing
+        if distributed:
+            tt = torch.tensor([dt_], dtype=torch.float64, device="cuda")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt_ = float(tt.item())
+        return dt_, k_ms
+
+    dt, kernel_ms = timed(n_in_flight, args.steps, args.warmup)
+    # the same frames one at a time (every rank takes part: the collectives must match): what round 1's `value` was, and the
+    # unoverlapped launch duration the counter-based figures refer to
+    one_at_a_time = timed(1, args.steps, min(args.warmup, 3)) if overlapped else None
+    if overlapped:
+        configure(n_in_flight)
 
     total_rays = float(rays_step)
     if distributed:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
         rr = torch.tensor([total_rays], dtype=torch.float64, device="cuda")
         dist.all_reduce(rr, op=dist.ReduceOp.SUM)
         total_rays = float(rr.item())
@@ -299,6 +327,12 @@ def main():
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
         value = total_rays * args.steps / dt / 1e6
+        # The roofline's launch duration is the kernel ALONE on the GPU (the one-frame-at-a-time pass, HIP events around
+        # every launch): with frames in flight a launch's begin-to-end time includes the time it shares the chip with its
+        # neighbours (n frames in flight: ~n x longer) and says nothing about the kernel.  Both are printed.
+        kernel_ms_in_flight = kernel_ms
+        if one_at_a_time:
+            kernel_ms = one_at_a_time[1]
         achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
         # which kernel the flags select (rtk_launch_primary)
         wide = bool(info.n_wide_nodes) and not (flags & rt.FLAG_BINARY_TREE)
@@ -334,6 +368,8 @@ def main():
                 traffic = tj.get("hbm_bytes_per_launch")
                 valu = {"busy": tj["valu_busy"], "lanes_active": tj["valu_lanes_active"],
                         "frac": round(tj["valu_busy"] * tj["valu_lanes_active"], 4)}
+                # counters are collected with launches serialised (rocprofv3 --pmc always does): HBM bytes per launch over
+                # the UNOVERLAPPED launch duration
                 if traffic and kernel_ms > 0:
                     hbm_frac = round(traffic / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
         except Exception as ex:
@@ -354,7 +390,7 @@ def main():
             "config": {"workload": args.workload, "resolution": f"{W}x{H}", "rays": (f"path tracing, {spp} spp, <= {segs} segments" if spp else "primary+shadow, 1 spp"),
                        "triangles": int(info.n_triangles), "bvh_nodes": int(info.n_nodes),
                        "rays_per_step_rank0": int(rays_step),
-                       "primary_hit_fraction": round(hits / max(cnt.rays_primary, 1), 4), "camera_radii": CAMERA_RADII, "frames_in_flight": args.in_flight if overlapped else 1,
+                       "primary_hit_fraction": round(hits / max(cnt.rays_primary, 1), 4), "camera_radii": CAMERA_RADII, "frames_in_flight": n_in_flight,
                        "backend": (dist.get_backend() if distributed else None), "rccl_ranks": (dist.get_world_size() if distributed and dist.get_backend() == "nccl" else None),
                        "parallelism": ("single-gpu" if not distributed else ("tiles64-roundrobin+host-pack+gather-to-rank0 (gloo rehearsal)" if gloo else "tiles64-roundrobin+hip-pack+one-gather-to-rank0+hip-unpack") if tiles else
                                        (f"sample-slices{world}+direct-reduce-scatter+gather-to-rank0" if samples else f"frames-dp{world}"))},
@@ -363,11 +399,19 @@ def main():
                          "achieved_is": "ALGORITHMIC bytes per launch / kernel time (SURVEY 8d); caches serve most of them, so it can exceed what HBM moves",
                          "hbm_frac": hbm_frac, "valu": valu, "pmc": pmc,
                          "kernel": kernel, "kernel_ms": round(kernel_ms, 4),
-                         **({"launches_overlapped": True, "note": "--in-flight > 1: launch durations overlap, achieved / frac describe shared time, not the kernel"} if overlapped else {}),
+                         **({"kernel_ms_is": "launch duration one frame at a time (HIP events around every launch of the pass after the timed region)",
+                             "kernel_ms_in_flight": round(kernel_ms_in_flight, 4),
+                             "kernel_ms_in_flight_is": f"the same events in the timed region, {n_in_flight} frames in flight: begin-to-end time of launches that share the GPU"} if overlapped else {}),
                          "algorithmic_bytes_per_launch": int(alg_bytes),
                          "node_visits": int(cnt.node_visits), "tri_tests": int(cnt.tri_tests),
                          "bytes_per_ray": round(alg_bytes / max(rays_step, 1), 1)},
         }
+        if one_at_a_time:
+            dt1, k1 = one_at_a_time
+            a1 = alg_bytes / (k1 * 1e-3) / 1e9 if k1 > 0 else 0.0
+            out["one_frame_at_a_time"] = {"value": round(total_rays * args.steps / dt1 / 1e6, 2), "unit": "Mrays/s", "ms_per_step": round(dt1 / args.steps * 1e3, 4),
+                                          "steps": args.steps, "kernel_ms": round(k1, 4), "achieved": round(a1, 2), "frac": round(a1 / HBM_PEAK_GBS, 5),
+                                          "note": "the same frames with --in-flight 1 (round 1's definition of value), measured after the timed region"}
         if not args.no_pipelined and not spp and world == 1 and not overlapped:
             # Outside the contract's timed region and never `value`: the same frames with TWO in flight inside this one
             # context (rt_set_frames_in_flight: a second set of frame buffers and a second stream, taken in turn).  The waves
@@ -394,31 +438,38 @@ def main():
                                     "note": "ONE context, rt_set_frames_in_flight(2): two sets of frame buffers and streams taken in turn by rt_render; not the contract's value"}
             except Exception as ex:                                              # never fail the bench line for it
                 out["pipelined"] = {"error": str(ex)[:120]}
-        if not args.no_north_star and not spp and world == 1 and not overlapped and args.workload == "sphere_field_10k_1080p_primary_shadow":
+        if not args.no_north_star and not spp and world == 1 and args.workload == "sphere_field_10k_1080p_primary_shadow":
             # north_star's own target scene (1 M-triangle icosphere soup, 1080p, primary + shadow, ">= 1 Grays/s"): a
-            # driver-timed figure for it, measured after the timed region like `pipelined`; never `value`
+            # driver-timed figure for it, measured after the timed region; never `value`.  Same frames in flight as the
+            # timed region, and one frame at a time beside it.
             try:
                 app_s, Ws, Hs = build_app(rt, "soup_1m_1080p_primary_shadow")
                 ctx_s = rt.Context(local_rank)
-                ctx_s.set_stream(stream.cuda_stream)
                 ctx_s.upload_scene(app_s.prepare_meshinfo())
                 ms_, ps_ = app_s.camera_view()
                 ctx_s.set_view(ms_, ps_, Ws, Hs)
                 ctx_s.render(flags=rt.FLAG_SHADOW | rt.FLAG_COUNTERS)
                 cs = ctx_s.counters()
                 rays_s = cs.rays_primary + cs.rays_shadow
-                for _ in range(5):
-                    ctx_s.render(flags=rt.FLAG_SHADOW)
-                ctx_s.synchronize()
-                t0 = time.perf_counter()
-                for _ in range(args.steps):
-                    ctx_s.render(flags=rt.FLAG_SHADOW)
-                ctx_s.synchronize()
-                dts = time.perf_counter() - t0
-                out["north_star_scene"] = {"workload": "soup_1m_1080p_primary_shadow", "value": round(rays_s * args.steps / dts / 1e6, 2),
-                                           "unit": "Mrays/s", "ms_per_step": round(dts / args.steps * 1e3, 4), "steps": args.steps,
+
+                def soup_ms(n_frames):
+                    ctx_s.set_frames_in_flight(n_frames)
+                    for _ in range(5):
+                        ctx_s.render(flags=rt.FLAG_SHADOW)
+                    ctx_s.synchronize()
+                    t0 = time.perf_counter()
+                    for _ in range(args.steps):
+                        ctx_s.render(flags=rt.FLAG_SHADOW)
+                    ctx_s.synchronize()
+                    return (time.perf_counter() - t0) / args.steps * 1e3
+                ms_n = soup_ms(n_in_flight)
+                out["north_star_scene"] = {"workload": "soup_1m_1080p_primary_shadow", "value": round(rays_s / ms_n / 1e3, 2),
+                                           "unit": "Mrays/s", "ms_per_step": round(ms_n, 4), "steps": args.steps, "frames_in_flight": n_in_flight,
                                            "rays_per_step": int(rays_s), "triangles": int(ctx_s.bvh_info().n_triangles),
                                            "target": ">= 1000 Mrays/s primary+shadow at 1080p on a 1M-triangle scene (BASELINE.json north_star)"}
+                if overlapped:
+                    ms_1 = soup_ms(1)
+                    out["north_star_scene"]["one_frame_at_a_time"] = {"value": round(rays_s / ms_1 / 1e3, 2), "ms_per_step": round(ms_1, 4)}
                 ctx_s.close(); app_s.close()
             except Exception as ex:                                              # never fail the bench line for it
                 out["north_star_scene"] = {"error": str(ex)[:120]}

@@ -69,9 +69,10 @@ int rt_set_stream(rt_ctx *ctx, void *hip_stream);
  * only); rt_synchronize waits for all.  Scene updates wait for every frame in flight.  Path-traced frames share one
  * accumulation buffer and are not overlapped; rt_read_accumulation and rt_resolve_accumulation wait for them too.
  * On a caller's stream (rt_set_stream) all sets run on that one stream and frames serialise.  Costs 24 B per pixel
- * per extra set.  The sets' own streams are created with different stream
- * priorities (normal, high, low, normal): one hardware-queue pool per priority is what keeps two sets off one queue,
- * where their frames would run strictly one after the other. */
+ * per extra set.  With n > 1 every set renders on a stream that has a hardware queue of its own (created with a CU mask
+ * of all compute units: ordinary streams share a few queues as the runtime sees fit, and two sets on one queue run
+ * their frames strictly one after the other); such streams are of HIP's default kind, so unlike the context's
+ * ordinary stream they also order against HIP's null stream. */
 int rt_set_frames_in_flight(rt_ctx *ctx, uint32_t n);
 /* The HIP stream (hipStream_t as void*) the frame rendered last runs on: the stream to order a consumer of
  * rt_device_buffers / rt_pack_tiles against (hipStreamWaitEvent, or make it the current stream of a framework), e.g. a

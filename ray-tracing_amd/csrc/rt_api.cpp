@@ -34,7 +34,8 @@ struct FrameSet {
     float *d_rgba = nullptr, *d_t = nullptr;
     uint32_t *d_prim = nullptr;
     unsigned long long *d_cnt = nullptr, *h_cnt = nullptr;
-    hipStream_t own_stream = nullptr;
+    hipStream_t own_stream = nullptr;      // set 0 only: the context's ordinary stream (one frame at a time)
+    hipStream_t flight_stream = nullptr;   // with frames in flight: a stream with a hardware queue of its own (rt_set_frames_in_flight)
     uint32_t coverage[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // what the buffers were last cleared for, compared field by field
     bool coverage_valid = false;
 };
@@ -98,6 +99,8 @@ struct rt_ctx {
     RtTune tune{};
     void *static_scratch = nullptr;       // device address of rt_kernels.hip's static scratch array on THIS device (rt_render_static)
     uint32_t static_accum_samples = 0;    // samples in the caller's accumulation buffer (rt_render_static)
+    uint32_t n_cus = 0;                   // compute units of the device (CU mask of the frames-in-flight streams)
+    uint32_t tune_flight_prio = 0;        // RT_TUNE_FLIGHT_PRIO=1: priority streams instead of CU-mask streams (A/B)
     uint32_t tune_wide = 0;               // build and walk the 4-wide quantised tree
     uint32_t tune_sample_batch = 16;      // path tracing: most samples of a pixel traced per launch (16, 4 or 1 are used)
     RtWideTree wide_host;
@@ -127,7 +130,8 @@ void free_dev(void *&p) { if (p) { (void)hipFree(p); p = nullptr; } }
 
 hipStream_t set_stream_of(const rt_ctx *c, uint32_t k) {
     if (c->use_null_stream) return nullptr;
-    return c->ext_stream ? c->ext_stream : c->fs[k].own_stream;
+    if (c->ext_stream) return c->ext_stream;
+    return c->n_sets > 1 && c->fs[k].flight_stream ? c->fs[k].flight_stream : c->fs[0].own_stream;
 }
 // the context's aliases point at set k
 void select_set(rt_ctx *c, uint32_t k) {
@@ -296,33 +300,19 @@ int rt_create(int device_ordinal, rt_ctx **out) {
         c->tune.path_sort = env("RT_TUNE_PATH_SORT", 0, 0, 6);
         c->tune.path_sort_key = env("RT_TUNE_PATH_SORT_KEY", 0, 0, 1);
         c->tune_wide = env("RT_TUNE_WIDE", 1, 0, 1);
+        c->tune_flight_prio = env("RT_TUNE_FLIGHT_PRIO", 0, 0, 1);
         c->tune_sample_batch = env("RT_TUNE_SAMPLE_BATCH", 16, 1, 16);
     }
     int rc = RT_OK;
     do {
         if ((e = hipSetDevice(device_ordinal)) != hipSuccess) { rc = fail(nullptr, RT_ERR_HIP, "hipSetDevice", e); break; }
-        // The streams of ALL frame sets are created here.  HIP maps streams onto a few hardware queues (4 per process on
-        // this pool) and two sets whose streams share a queue never overlap (kernel trace of bench.py --in-flight 2 under
-        // RCCL: sets 0 and 1 on one queue, frames strictly serial).  Which queue a stream gets is the runtime's choice,
-        // except that each stream priority has a queue pool of its own: sets 0, 1, 2 take the normal, the high and the low
-        // priority, so the first three sets cannot share; set 3 is normal again.  Set 0 (the only one unless
-        // rt_set_frames_in_flight is called) is an ordinary stream.
-        int prio_least = 0, prio_greatest = 0;
-        if ((e = hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest)) != hipSuccess) { rc = fail(nullptr, RT_ERR_HIP, "hipDeviceGetStreamPriorityRange", e); break; }
-        const int prio[RT_MAX_IN_FLIGHT] = {0, prio_greatest, prio_least, 0};
-        for (int k = 0; k < RT_MAX_IN_FLIGHT; ++k)
-            if ((e = hipStreamCreateWithPriority(&c->fs[k].own_stream, hipStreamNonBlocking, prio[k])) != hipSuccess) break;
-        if (e != hipSuccess) { rc = fail(nullptr, RT_ERR_HIP, "hipStreamCreateWithPriority", e); break; }
+        // set 0's ordinary stream; the streams of frames in flight are made by rt_set_frames_in_flight
+        if ((e = hipStreamCreateWithFlags(&c->fs[0].own_stream, hipStreamNonBlocking)) != hipSuccess) { rc = fail(nullptr, RT_ERR_HIP, "hipStreamCreate", e); break; }
+        c->n_cus = (uint32_t)prop.multiProcessorCount;
         c->own_stream = c->fs[0].own_stream;
         if ((e = hipMalloc((void **)&c->fs[0].d_cnt, RT_CNT_N * sizeof(unsigned long long))) != hipSuccess) { rc = fail(nullptr, RT_ERR_HIP, "hipMalloc counters", e); break; }
         if ((e = hipHostMalloc((void **)&c->fs[0].h_cnt, RT_CNT_N * sizeof(unsigned long long), hipHostMallocDefault)) != hipSuccess) { rc = fail(nullptr, RT_ERR_HIP, "hipHostMalloc counters", e); break; }
         std::memset(c->fs[0].h_cnt, 0, RT_CNT_N * sizeof(unsigned long long));
-        // ... and each is used once right away: a stream takes its hardware queue at its first submission, which is better
-        // paid here than inside the first timed frame
-        for (FrameSet &f : c->fs)
-            if ((e = hipMemsetAsync(c->fs[0].d_cnt, 0, sizeof(unsigned long long), f.own_stream)) != hipSuccess ||
-                (e = hipStreamSynchronize(f.own_stream)) != hipSuccess) break;
-        if (e != hipSuccess) { rc = fail(nullptr, RT_ERR_HIP, "first use of the frame sets' streams", e); break; }
         select_set(c, 0);
         // the static scratch array of rt_render_static: every device holds its own copy at its own address, so the
         // address is asked for here, once per context, with this context's device current
@@ -345,7 +335,10 @@ int rt_destroy(rt_ctx *c) {
     }
     for (hipEvent_t ev : c->ev) (void)hipEventDestroy(ev);
     for (hipEvent_t ev : c->ev_update) if (ev) (void)hipEventDestroy(ev);
-    for (FrameSet &f : c->fs) if (f.own_stream) (void)hipStreamDestroy(f.own_stream);
+    for (FrameSet &f : c->fs) {
+        if (f.own_stream) (void)hipStreamDestroy(f.own_stream);
+        if (f.flight_stream) (void)hipStreamDestroy(f.flight_stream);
+    }
     delete c;
     return RT_OK;
 }
@@ -365,9 +358,31 @@ int rt_set_frames_in_flight(rt_ctx *c, uint32_t n) {
     if (n == 0 || n > RT_MAX_IN_FLIGHT) return fail(c, RT_ERR_ARG, "rt_set_frames_in_flight: 1..4 frames");
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, sync_all(c));
-    for (uint32_t k = 1; k < n; ++k) {      // sets beyond the first get their stream, counters and (if a view exists) frame buffers
+    // Frames overlap only if their streams sit on different hardware queues, and HIP maps ordinary streams onto few of
+    // them (4 per process on this pool) as it sees fit: next to RCCL's streams two sets shared one queue and their frames
+    // ran strictly one after the other (kernel trace).  A stream created with a CU mask gets a
+    // hardware queue of its own, so with n > 1 EVERY set (set 0 too) renders on such a stream, mask = all CUs.  These
+    // streams are of HIP's default kind: they also order against the null stream.  Should the call fail, stream
+    // priorities are the fallback (one queue pool per priority: normal, high, low keep three sets apart).
+    for (uint32_t k = 0; k < n && n > 1; ++k) {
         FrameSet &f = c->fs[k];
-        if (!f.own_stream) HIPCHK(c, hipStreamCreateWithFlags(&f.own_stream, hipStreamNonBlocking));
+        if (f.flight_stream) continue;
+        uint32_t mask[32];
+        for (uint32_t &w : mask) w = 0xFFFFFFFFu;
+        const uint32_t words = std::min<uint32_t>(32u, (c->n_cus + 31u) / 32u);
+        if (c->tune_flight_prio || hipExtStreamCreateWithCUMask(&f.flight_stream, words, mask) != hipSuccess) {
+            (void)hipGetLastError();
+            int least = 0, greatest = 0;
+            HIPCHK(c, hipDeviceGetStreamPriorityRange(&least, &greatest));
+            const int prio[RT_MAX_IN_FLIGHT] = {0, greatest, least, 0};
+            HIPCHK(c, hipStreamCreateWithPriority(&f.flight_stream, hipStreamNonBlocking, prio[k]));
+        }
+        // first use now (a stream takes its queue at its first submission), not inside the first timed frame
+        HIPCHK(c, hipMemsetAsync(c->fs[0].d_cnt, 0, sizeof(unsigned long long), f.flight_stream));
+        HIPCHK(c, hipStreamSynchronize(f.flight_stream));
+    }
+    for (uint32_t k = 1; k < n; ++k) {      // sets beyond the first get their counters and (if a view exists) frame buffers
+        FrameSet &f = c->fs[k];
         if (!f.d_cnt) HIPCHK(c, hipMalloc((void **)&f.d_cnt, RT_CNT_N * sizeof(unsigned long long)));
         if (!f.h_cnt) {
             HIPCHK(c, hipHostMalloc((void **)&f.h_cnt, RT_CNT_N * sizeof(unsigned long long), hipHostMallocDefault));
@@ -381,7 +396,7 @@ int rt_set_frames_in_flight(rt_ctx *c, uint32_t n) {
         }
     }
     c->n_sets = n;
-    if (c->cur_set >= n) select_set(c, 0);
+    select_set(c, c->cur_set >= n ? 0 : c->cur_set);     // the aliases, the stream among them, follow the new configuration
     return RT_OK;
 }
 

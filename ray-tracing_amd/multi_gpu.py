@@ -143,28 +143,35 @@ class TileGather:
         self.slot = tile_slot_floats(self.rect[2], self.rect[3], tile, world)
         if ctx is not None:
             assert ctx.tile_slot_bytes(world, tile) == self.slot * 4
-        # one set of message buffers per frame in flight: frame k's gather may still be under way when frame k + 1 packs
-        self.sets = []
-        for _ in range(max(1, in_flight)):
-            send = torch.zeros(self.slot, dtype=torch.float32, device=device)
-            recv = torch.zeros(self.slot * world, dtype=torch.float32, device=device) if rank == 0 else None
-            self.sets.append((send, recv, list(recv.view(world, self.slot).unbind(0)) if rank == 0 else None))
-        self.turn = 0
+        # one set of message buffers per frame in flight: frame k's gather may still be under way when frame k + 1 packs.
+        # On the device path a set belongs to ONE stream (combine_in_flight hands them out per rt_get_stream handle), so
+        # a set's reuse is ordered behind its last use by the stream itself.
+        self.in_flight = max(1, in_flight)
+        self._device = device
+        self.sets = [self._new_set() for _ in range(self.in_flight)]
         self.send, self.recv, self.recv_list = self.sets[0]
-        self._streams = {}
+        self._by_stream = {}
+
+    def _new_set(self):
+        import torch
+        send = torch.zeros(self.slot, dtype=torch.float32, device=self._device)
+        recv = torch.zeros(self.slot * self.world, dtype=torch.float32, device=self._device) if self.rank == 0 else None
+        return (send, recv, list(recv.view(self.world, self.slot).unbind(0)) if self.rank == 0 else None)
 
     def combine_in_flight(self):
-        """Device path with rt_set_frames_in_flight(n > 1) and the context on its OWN streams: pack, gather and unpack of the
-        frame rendered last are ordered on THAT frame's stream (made torch's current stream for the duration, so the
-        collective waits for the pack and the unpack for the collective), with this frame's own message buffers -- the next
-        rt_render goes to the next set's stream and overlaps with this frame's exchange."""
+        """Device path: pack, gather and unpack of the frame rendered last, ordered on THAT frame's stream (rt_get_stream,
+        made torch's current stream for the three calls, so the collective waits for the pack and the unpack for the
+        collective) with the message buffers that belong to that stream.  With rt_set_frames_in_flight(n > 1) and the
+        context on its own streams the next rt_render goes to the next set's stream and overlaps with this exchange;
+        with one frame in flight (or a caller's stream) it is combine() on the context's stream."""
         import torch
         ptr = self.ctx.get_stream()
-        if ptr not in self._streams:
-            self._streams[ptr] = torch.cuda.ExternalStream(ptr)
-        self.send, self.recv, self.recv_list = self.sets[self.turn]
-        self.turn = (self.turn + 1) % len(self.sets)
-        with torch.cuda.stream(self._streams[ptr]):
+        if ptr not in self._by_stream:
+            k = len(self._by_stream)
+            bufs = self.sets[k] if k < len(self.sets) else self._new_set()     # a stream not seen before (the context was re-configured)
+            self._by_stream[ptr] = (torch.cuda.ExternalStream(ptr) if ptr else torch.cuda.default_stream(), bufs)
+        st, (self.send, self.recv, self.recv_list) = self._by_stream[ptr]
+        with torch.cuda.stream(st):
             return self.combine(None)
 
     def combine(self, frame=None):

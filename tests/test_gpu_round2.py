@@ -304,7 +304,8 @@ def test_get_stream_and_tile_exchange_with_frames_in_flight():
         for _ in range(4):
             ctx.render(flags=rt.FLAG_SHADOW)
             seen.append(ctx.get_stream())
-        assert seen[0] != seen[1] and seen[0] == seen[2] and seen[1] == seen[3] and 0 not in seen and own in seen
+        assert seen[0] != seen[1] and seen[0] == seen[2] and seen[1] == seen[3] and 0 not in seen
+        assert own not in seen                                   # with frames in flight every set has a stream with a queue of its own
         side = torch.cuda.Stream(device=0)
         ctx.set_stream(side.cuda_stream)
         ctx.render(flags=rt.FLAG_SHADOW)
@@ -336,6 +337,8 @@ def test_get_stream_and_tile_exchange_with_frames_in_flight():
                 peer_stream.wait_event(taken)                     # the message buffer is free again two frames later
                 k += 1
             assert bitwise_equal(ctx.read_radiance(), full[(k - 1) % len(cams)])
+        ctx.set_frames_in_flight(1)
+        assert ctx.get_stream() == own                            # one frame at a time: the context's ordinary stream again
 
 
 @pytest.mark.parametrize("env", [{"RT_TUNE_POOL_DEP": "16"}, {"RT_TUNE_POOL_DEP": "24", "RT_TUNE_POOL_PICK": "8", "RT_TUNE_POOL_DRAIN": "1"},

@@ -201,8 +201,9 @@ def main():
     gloo_rehearsal = distributed and os.environ.get("BENCH_BACKEND", "nccl") != "nccl"
 
     def frames_in_flight():
-        """Path-traced frames share one accumulation buffer and never overlap; the gloo rehearsal stages through the host."""
-        if len(WORKLOADS[args.workload]) > 5 or gloo_rehearsal:
+        """The gloo rehearsal stages through the host, and the sample-slice reduction reads the accumulation buffer on torch's
+        stream: one frame at a time there.  Path-traced frames overlap two at a time whatever n > 1 says (rt_render)."""
+        if gloo_rehearsal or samples:
             return 1
         return args.in_flight
     n_in_flight = frames_in_flight()

@@ -66,10 +66,12 @@ int rt_set_stream(rt_ctx *ctx, void *hip_stream);
  * the 7.2 M-triangle scene, one scene copy instead of the two that two contexts need).  The reference's render node
  * (src/node.rs:29-79) submits one frame after the other the same way and lets the GPU queue overlap them.
  * rt_read_*, rt_device_buffers, rt_pack_tiles and rt_get_counters refer to the frame rendered LAST (they wait for it
- * only); rt_synchronize waits for all.  Scene updates wait for every frame in flight.  Path-traced frames share one
- * accumulation buffer and are not overlapped; rt_read_accumulation and rt_resolve_accumulation wait for them too.
- * On a caller's stream (rt_set_stream) all sets run on that one stream and frames serialise.  Costs 24 B per pixel
- * per extra set.  With n > 1 every set renders on a stream that has a hardware queue of its own (created with a CU mask
+ * only); rt_synchronize waits for all.  Scene updates wait for every frame in flight.  Path-traced frames alternate
+ * between two sets and share ONE accumulation buffer: a frame's tracing overlaps with the frame before it, its
+ * additions to the running sums (and a restart's clear) wait for that frame's end, so sums and RT_FLAG_ACCUMULATE
+ * chains are those of frames rendered one after the other; rt_read_accumulation and rt_resolve_accumulation wait for
+ * them.  On a caller's stream (rt_set_stream) all sets run on that one stream and frames serialise.  Costs 24 B per
+ * pixel per extra set, and a second set of path queues (120 B per path of a batch) once path-traced frames overlap.  With n > 1 every set renders on a stream that has a hardware queue of its own (created with a CU mask
  * of all compute units: ordinary streams share a few queues as the runtime sees fit, and two sets on one queue run
  * their frames strictly one after the other); such streams are of HIP's default kind, so unlike the context's
  * ordinary stream they also order against HIP's null stream. */

@@ -38,7 +38,16 @@ struct FrameSet {
     hipStream_t flight_stream = nullptr;   // with frames in flight: a stream with a hardware queue of its own (rt_set_frames_in_flight)
     uint32_t coverage[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // what the buffers were last cleared for, compared field by field
     bool coverage_valid = false;
+    // path tracing: queues (2, ping-pong), the per-sample contribution planes of a batch of samples, hit records.  Sets 0 and
+    // 1 only (RT_PATH_SETS): a path-traced frame's tracing overlaps with the frame before it, its additions to the ONE
+    // accumulation buffer wait for that frame's (rt_render)
+    QueueMem q[2];
+    size_t q_capacity = 0;
+    float *d_contrib = nullptr;
+    uint32_t contrib_planes = 0;
+    float *d_hits = nullptr;              // one 16-B hit record per queued path (k_path_trace -> k_path_shade)
 };
+#define RT_PATH_SETS 2u
 
 struct rt_ctx {
     int device = 0;
@@ -83,12 +92,8 @@ struct rt_ctx {
     uint32_t accum_cov[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // the coverage the running sums were started under
     bool accum_dirty = false;        // camera moved: the next path-traced frame restarts accumulation
 
-    // path queues (2, ping-pong) and the per-sample contribution planes of a batch of samples
-    QueueMem q[2];
-    size_t q_capacity = 0;
-    float *d_contrib = nullptr;
-    uint32_t contrib_planes = 0;
-    float *d_hits = nullptr;              // one 16-B hit record per queued path (k_path_trace -> k_path_shade)
+    hipEvent_t ev_accum = nullptr;        // recorded at the end of every path-traced frame: the next one's additions wait for it
+    bool accum_pending = false;
 
     // counters
     unsigned long long *d_cnt = nullptr;
@@ -149,11 +154,15 @@ hipError_t sync_all(rt_ctx *c) {
     }
     return first;
 }
-// The accumulation buffer belongs to the path-traced frames, which all run on set 0 (rt_render): a reader that arrives
-// after a later primary frame on another set has to wait for set 0's stream, not only for the frame rendered last.
+// The accumulation buffer belongs to the path-traced frames, which run on sets 0 and 1 (rt_render): a reader that arrives
+// after a later primary frame on another set has to wait for those sets' streams, not only for the frame rendered last.
 hipError_t wait_path_frames(rt_ctx *c) {
-    if (c->n_sets > 1 && c->cur_set != 0) return hipStreamSynchronize(set_stream_of(c, 0));
-    return hipSuccess;
+    hipError_t first = hipSuccess;
+    for (uint32_t k = 0; k < c->n_sets && k < RT_PATH_SETS && c->n_sets > 1; ++k) {
+        hipError_t e = hipStreamSynchronize(set_stream_of(c, k));
+        if (e != hipSuccess && first == hipSuccess) first = e;
+    }
+    return first;
 }
 void invalidate_coverage(rt_ctx *c) { for (FrameSet &f : c->fs) f.coverage_valid = false; }
 
@@ -179,13 +188,15 @@ void free_frame(rt_ctx *c) {
     c->d_rgba = nullptr; c->d_t = nullptr; c->d_prim = nullptr;
     p = c->d_accum; free_dev(p); c->d_accum = nullptr;
     p = c->d_bgra; free_dev(p); c->d_bgra = nullptr;
-    for (int i = 0; i < 2; ++i) {
-        p = c->q[i].f; free_dev(p); c->q[i].f = nullptr;
-        p = c->q[i].u; free_dev(p); c->q[i].u = nullptr;
+    for (FrameSet &f : c->fs) {
+        for (int i = 0; i < 2; ++i) {
+            p = f.q[i].f; free_dev(p); f.q[i].f = nullptr;
+            p = f.q[i].u; free_dev(p); f.q[i].u = nullptr;
+        }
+        f.q_capacity = 0;
+        p = f.d_contrib; free_dev(p); f.d_contrib = nullptr; f.contrib_planes = 0;
+        p = f.d_hits; free_dev(p); f.d_hits = nullptr;
     }
-    c->q_capacity = 0;
-    p = c->d_contrib; free_dev(p); c->d_contrib = nullptr; c->contrib_planes = 0;
-    p = c->d_hits; free_dev(p); c->d_hits = nullptr;
     c->n_px = 0;
 }
 
@@ -210,26 +221,26 @@ RtPathQueue queue_view(const QueueMem &m, size_t cap) {
 }
 
 // path queues for `batch` samples of every pixel in flight, and the batch's per-sample contribution planes
-int ensure_queues(rt_ctx *c, uint32_t batch) {
+int ensure_queues(rt_ctx *c, FrameSet &f, uint32_t batch) {
     const size_t need = c->n_px * batch;
-    if (c->q_capacity < need || !c->q[0].f) {
+    if (f.q_capacity < need || !f.q[0].f) {
         for (int i = 0; i < 2; ++i) {
-            void *p = c->q[i].f; free_dev(p); c->q[i].f = nullptr;
-            p = c->q[i].u; free_dev(p); c->q[i].u = nullptr;
+            void *p = f.q[i].f; free_dev(p); f.q[i].f = nullptr;
+            p = f.q[i].u; free_dev(p); f.q[i].u = nullptr;
         }
-        c->q_capacity = 0;
-        { void *p = c->d_hits; free_dev(p); c->d_hits = nullptr; }
+        f.q_capacity = 0;
+        { void *p = f.d_hits; free_dev(p); f.d_hits = nullptr; }
         for (int i = 0; i < 2; ++i) {
-            HIPCHK(c, hipMalloc((void **)&c->q[i].f, need * 9 * sizeof(float)));
-            HIPCHK(c, hipMalloc((void **)&c->q[i].u, need * 2 * sizeof(uint32_t)));
+            HIPCHK(c, hipMalloc((void **)&f.q[i].f, need * 9 * sizeof(float)));
+            HIPCHK(c, hipMalloc((void **)&f.q[i].u, need * 2 * sizeof(uint32_t)));
         }
-        HIPCHK(c, hipMalloc((void **)&c->d_hits, need * 16));
-        c->q_capacity = need;
+        HIPCHK(c, hipMalloc((void **)&f.d_hits, need * 16));
+        f.q_capacity = need;
     }
-    if (c->contrib_planes < batch || !c->d_contrib) {
-        void *p = c->d_contrib; free_dev(p); c->d_contrib = nullptr; c->contrib_planes = 0;
-        HIPCHK(c, hipMalloc((void **)&c->d_contrib, need * 16));
-        c->contrib_planes = batch;
+    if (f.contrib_planes < batch || !f.d_contrib) {
+        void *p = f.d_contrib; free_dev(p); f.d_contrib = nullptr; f.contrib_planes = 0;
+        HIPCHK(c, hipMalloc((void **)&f.d_contrib, need * 16));
+        f.contrib_planes = batch;
     }
     return RT_OK;
 }
@@ -313,6 +324,7 @@ int rt_create(int device_ordinal, rt_ctx **out) {
         if ((e = hipMalloc((void **)&c->fs[0].d_cnt, RT_CNT_N * sizeof(unsigned long long))) != hipSuccess) { rc = fail(nullptr, RT_ERR_HIP, "hipMalloc counters", e); break; }
         if ((e = hipHostMalloc((void **)&c->fs[0].h_cnt, RT_CNT_N * sizeof(unsigned long long), hipHostMallocDefault)) != hipSuccess) { rc = fail(nullptr, RT_ERR_HIP, "hipHostMalloc counters", e); break; }
         std::memset(c->fs[0].h_cnt, 0, RT_CNT_N * sizeof(unsigned long long));
+        if ((e = hipEventCreateWithFlags(&c->ev_accum, hipEventDisableTiming)) != hipSuccess) { rc = fail(nullptr, RT_ERR_HIP, "hipEventCreate", e); break; }
         select_set(c, 0);
         // the static scratch array of rt_render_static: every device holds its own copy at its own address, so the
         // address is asked for here, once per context, with this context's device current
@@ -335,6 +347,7 @@ int rt_destroy(rt_ctx *c) {
     }
     for (hipEvent_t ev : c->ev) (void)hipEventDestroy(ev);
     for (hipEvent_t ev : c->ev_update) if (ev) (void)hipEventDestroy(ev);
+    if (c->ev_accum) (void)hipEventDestroy(c->ev_accum);
     for (FrameSet &f : c->fs) {
         if (f.own_stream) (void)hipStreamDestroy(f.own_stream);
         if (f.flight_stream) (void)hipStreamDestroy(f.flight_stream);
@@ -962,8 +975,11 @@ static uint32_t batch_of(const rt_ctx *c, const RenderTargets &T, uint32_t left)
 }
 
 // The launches of one frame.  No allocation, no synchronisation: everything is enqueued on the context's stream.
+// Path tracing: the tracing launches touch only this frame's own queues and contribution planes; the running sums are ONE
+// buffer, so the first thing that touches them -- the restart's clear (restart_accum) or the first batch's additions --
+// waits for wait_accum (the end of the path-traced frame before this one, possibly on another set's stream; may be NULL).
 static int launch_frame(rt_ctx *c, const rt_render_params &P, const RtShardDev &sh, bool partial, const RenderTargets &T,
-                        uint32_t *accum_samples, uint32_t *launches_out) {
+                        uint32_t *accum_samples, uint32_t *launches_out, bool restart_accum = false, hipEvent_t wait_accum = nullptr) {
     HIPCHK(c, hipMemsetAsync(T.cnt, 0, RT_CNT_N * sizeof(unsigned long long), c->stream));
     uint32_t launches = 0;
     if (!(P.flags & RT_FLAG_PATH_TRACE)) {
@@ -998,6 +1014,10 @@ static int launch_frame(rt_ctx *c, const rt_render_params &P, const RtShardDev &
                 launches += split ? 2u : 1u;
                 int tmp = in; in = out; out = tmp;
             }
+            if (s == 0) {
+                if (wait_accum) HIPCHK(c, hipStreamWaitEvent(c->stream, wait_accum, 0));
+                if (restart_accum) HIPCHK(c, hipMemsetAsync(T.accum, 0, c->n_px * 16, c->stream));
+            }
             HIPCHK(c, rtk_launch_accumulate_batch(c->stream, T.accum, T.contrib, c->n_px, b));
         }
         *accum_samples += P.spp;
@@ -1016,16 +1036,15 @@ int rt_render(rt_ctx *c, const rt_render_params *params) {
     if (rc != RT_OK) return rc;
     HIPCHK(c, hipSetDevice(c->device));
 
-    // Frames in flight: primary / shadow frames take the sets in turn (each set has its own stream, so frame k + 1 fills
-    // the compute units frame k's last regions leave idle); path-traced frames share ONE accumulation buffer and the path
-    // queues, so they all run on set 0, after everything else in flight.
+    // Frames in flight: frames take the sets in turn (each set has its own stream, so frame k + 1 fills the compute units
+    // frame k's last regions leave idle).  Path-traced frames alternate between the first two sets only (their queues are
+    // large: 120 B per path; two in flight give what there is to gain, tools/path_two_contexts.py) and share ONE
+    // accumulation buffer: a frame's tracing overlaps with the frame before it, its additions wait for that frame's end.
     const bool path_frame = (P.flags & RT_FLAG_PATH_TRACE) != 0;
-    if (c->n_sets > 1) {
-        if (path_frame) { HIPCHK(c, sync_all(c)); select_set(c, 0); }
-        else select_set(c, (c->cur_set + 1) % c->n_sets);
-    }
+    if (c->n_sets > 1) select_set(c, (c->cur_set + 1) % (path_frame ? std::min(c->n_sets, RT_PATH_SETS) : c->n_sets));
     FrameSet &F = c->fs[c->cur_set];
     RenderTargets T{};
+    bool restart_accum = false;
     T.rgba = c->d_rgba; T.accum = c->d_accum; T.t = c->d_t; T.prim = c->d_prim; T.cnt = c->d_cnt;
     // Pixels this call does not cover (outside the viewport, other ranks' tiles) must read as cleared; clear only
     // when the coverage changes.
@@ -1040,17 +1059,18 @@ int rt_render(rt_ctx *c, const rt_render_params *params) {
         T.max_batch = c->tune_sample_batch;
         T.q_cap = (size_t)64 << 20;                      // at most 64 M queued paths
         const uint32_t batch = batch_of(c, T, P.spp);
-        rc = ensure_queues(c, batch);
+        rc = ensure_queues(c, F, batch);
         if (rc != RT_OK) return rc;
-        T.q_cap = c->q_capacity;
-        T.max_batch = std::min(c->tune_sample_batch, c->contrib_planes);
-        T.qa = queue_view(c->q[0], c->q_capacity); T.qb = queue_view(c->q[1], c->q_capacity);
-        T.contrib = c->d_contrib;
-        T.hits = c->d_hits;
+        T.q_cap = F.q_capacity;
+        T.max_batch = std::min(c->tune_sample_batch, F.contrib_planes);
+        T.qa = queue_view(F.q[0], F.q_capacity); T.qb = queue_view(F.q[1], F.q_capacity);
+        T.contrib = F.d_contrib;
+        T.hits = F.d_hits;
         // the running sums restart unless asked to go on -- and also when the camera or the geometry moved or the coverage
-        // is not the one they were started under (intent of src/scene.rs:94-96)
+        // is not the one they were started under (intent of src/scene.rs:94-96); the clear is enqueued by launch_frame,
+        // behind the frame before this one
         if (!(P.flags & RT_FLAG_ACCUMULATE) || c->accum_dirty || std::memcmp(cov, c->accum_cov, sizeof cov) != 0) {
-            HIPCHK(c, hipMemsetAsync(c->d_accum, 0, c->n_px * 16, c->stream));
+            restart_accum = true;
             c->accum_samples = 0;
             c->accum_dirty = false;
             std::memcpy(c->accum_cov, cov, sizeof cov);
@@ -1071,8 +1091,12 @@ int rt_render(rt_ctx *c, const rt_render_params *params) {
         HIPCHK(c, hipEventRecord(ev0, c->stream));
     }
     uint32_t launches = 0;
-    rc = launch_frame(c, P, sh, partial, T, &c->accum_samples, &launches);
+    rc = launch_frame(c, P, sh, partial, T, &c->accum_samples, &launches, restart_accum, path_frame && c->accum_pending ? c->ev_accum : nullptr);
     if (rc != RT_OK) return rc;
+    if (path_frame) {
+        HIPCHK(c, hipEventRecord(c->ev_accum, c->stream));
+        c->accum_pending = true;
+    }
     if (timed) {
         HIPCHK(c, hipEventRecord(ev1, c->stream));
         c->ev_used += 2; c->counters.kernel_launches += launches;

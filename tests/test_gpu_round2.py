@@ -251,6 +251,14 @@ def test_frames_in_flight_inside_one_context(n):
         acc = ctx.read_accumulation()
         acc_o, _ = orc.render_path(oracle_scene(scene), orc.make_view(m, p, 640, 360), 5, 4, seed=4, threads=16)
         assert bitwise_equal(acc, acc_o)
+        # path-traced frames back to back: they alternate between two sets, a frame's tracing overlaps with the frame before
+        # it and its additions to the one accumulation buffer wait for that frame's -- five one-sample frames give the sums
+        # of five samples, and a restart in between (no RT_FLAG_ACCUMULATE) clears behind the frame before it
+        ctx.render(flags=rt.FLAG_PATH_TRACE, spp=2, max_segments=4, seed=9)
+        for k in range(5):
+            ctx.render(flags=rt.FLAG_PATH_TRACE | (rt.FLAG_ACCUMULATE if k else 0), spp=1, sample_first=k, max_segments=4, seed=4)
+        assert bitwise_equal(ctx.read_accumulation(), acc_o)
+        assert bitwise_equal(ctx.read_radiance(), orc.resolve(acc_o, 5))
         # timed frames on every set, counters asked for without a synchronize in between: all event pairs are complete
         for _ in range(n + 1):
             ctx.render(flags=rt.FLAG_SHADOW | rt.FLAG_TIME_KERNELS)

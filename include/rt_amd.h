@@ -71,10 +71,11 @@ int rt_set_stream(rt_ctx *ctx, void *hip_stream);
  * additions to the running sums (and a restart's clear) wait for that frame's end, so sums and RT_FLAG_ACCUMULATE
  * chains are those of frames rendered one after the other; rt_read_accumulation and rt_resolve_accumulation wait for
  * them.  On a caller's stream (rt_set_stream) all sets run on that one stream and frames serialise.  Costs 24 B per
- * pixel per extra set, and a second set of path queues (120 B per path of a batch) once path-traced frames overlap.  With n > 1 every set renders on a stream that has a hardware queue of its own (created with a CU mask
- * of all compute units: ordinary streams share a few queues as the runtime sees fit, and two sets on one queue run
- * their frames strictly one after the other); such streams are of HIP's default kind, so unlike the context's
- * ordinary stream they also order against HIP's null stream. */
+ * pixel per extra set, and a second set of path queues (120 B per path of a batch) once path-traced frames overlap.
+ * With n > 1 every set renders on a stream that has a hardware queue of its own (created with a CU mask of all
+ * compute units: ordinary streams share a few queues as the runtime sees fit, and two sets on one queue run their
+ * frames strictly one after the other); such streams are of HIP's default kind, so unlike the context's ordinary
+ * stream they also order against HIP's null stream. */
 int rt_set_frames_in_flight(rt_ctx *ctx, uint32_t n);
 /* The HIP stream (hipStream_t as void*) the frame rendered last runs on: the stream to order a consumer of
  * rt_device_buffers / rt_pack_tiles against (hipStreamWaitEvent, or make it the current stream of a framework), e.g. a

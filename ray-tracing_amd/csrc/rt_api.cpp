@@ -982,6 +982,7 @@ static int launch_frame(rt_ctx *c, const rt_render_params &P, const RtShardDev &
                         uint32_t *accum_samples, uint32_t *launches_out, bool restart_accum = false, hipEvent_t wait_accum = nullptr) {
     HIPCHK(c, hipMemsetAsync(T.cnt, 0, RT_CNT_N * sizeof(unsigned long long), c->stream));
     uint32_t launches = 0;
+    c->tune.frames_in_flight = (c->ext_stream || c->use_null_stream) ? 1u : c->n_sets;     // on one stream frames do not overlap
     if (!(P.flags & RT_FLAG_PATH_TRACE)) {
         HIPCHK(c, rtk_launch_primary(c->stream, c->S, c->V, sh, P.flags, T.rgba, T.prim, T.t, T.cnt, c->tune));
         launches = 1;

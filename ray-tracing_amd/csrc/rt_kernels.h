@@ -17,7 +17,8 @@ uint32_t rtk_primary_blocks(const RtShardDev &sh);
 struct RtTune {
     uint32_t persist_blocks;   // grid of the persistent path kernels (CUs x resident blocks per CU)
     uint32_t cus;              // compute units of the device
-    uint32_t blocks_per_cu;    // k_stream: resident blocks per CU; 0 = by BVH size (rtk_launch_primary)
+    uint32_t blocks_per_cu;    // k_stream: resident blocks per CU; 0 = by BVH size and frames in flight (rtk_launch_primary)
+    uint32_t frames_in_flight; // sets rt_render rotates over (rt_set_frames_in_flight), 1 on a caller's stream
     uint32_t refill_min;       // idle lanes in a wave that trigger a refill (64 = whole 8x8 blocks only)
     uint32_t finish_min;       // ended rays in a wave that trigger a hand-over
     uint32_t vote_node, vote_tri;   // relative issue cost of a node step / a triangle step (phase vote)

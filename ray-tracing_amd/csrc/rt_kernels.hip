@@ -1811,7 +1811,10 @@ hipError_t rtk_launch_primary(hipStream_t st, const RtSceneDev &S, const RtViewD
         uint32_t per_cu = tune.blocks_per_cu;
         const bool w_ = S.n_wide != 0u && !(flags & RT_FLAG_BINARY_TREE);
         const size_t tree = (size_t)(w_ ? S.n_wide : S.n_nodes) * sizeof(RtBvhNode) + (size_t)S.n_recs * sizeof(RtTriRecord);
-        if (per_cu == 0) per_cu = tree <= ((size_t)4 << 20) ? 3u : (tree <= ((size_t)16 << 20) ? 5u : 8u);
+        // With 3-4 frames in flight a CU holds blocks of several launches; 5 per launch instead of 8 leave room for the next
+        // frames' blocks and each launch a shorter tail (tools/ab_in_flight_knobs.py, 4 in flight: bench scene 0.603 -> 0.597 ms,
+        // 1 M-triangle soup 0.412 -> 0.396; one frame at a time the same setting costs 10 %)
+        if (per_cu == 0) per_cu = tree <= ((size_t)4 << 20) ? 3u : (tree <= ((size_t)16 << 20) || tune.frames_in_flight >= 3u ? 5u : 8u);
         if (per_cu > RT_STREAM_WAVES) per_cu = RT_STREAM_WAVES;      // what a CU can hold: later blocks would only find empty queues
         uint32_t need = (sh.n_owned * sh.tile * sh.tile + RT_BLOCK - 1) / RT_BLOCK;
         uint32_t grid = tune.cus * per_cu < need ? tune.cus * per_cu : need;

@@ -206,6 +206,15 @@ int rt_read_accumulation(rt_ctx *ctx, float *accum, size_t n_floats);
  * Byte work, exact: a colour byte is the correctly rounded round(255 * srgb_oetf(x)) (threshold table generated by
  * tools/gen_srgb_table.py), alpha is floor(255 * clamp(a) + 0.5); NaN encodes as 0. */
 int rt_encode_bgra8_srgb(rt_ctx *ctx, const float *rgba, size_t n_pixels, uint8_t *bgra);
+/* Presentation that does not stall frames in flight (what the colour-attachment write of src/node.rs:63-69 is to a
+ * render graph that keeps submitting).  rt_present_async encodes the frame rendered LAST into Bgra8UnormSrgb bytes and
+ * enqueues their copy into host_bgra (W*H*4 bytes; pinned or registered host memory for a copy that really is
+ * asynchronous), all on that frame's stream, and returns at once; *ticket names the frame's set (0..3).
+ * rt_present_wait blocks until the bytes of that ticket have arrived.  A ticket is good until its set is presented
+ * again, i.e. for the next n - 1 calls with n frames in flight; host_bgra must stay untouched until its wait returns.
+ * The bytes are those rt_read_bgra8_srgb returns for the same frame. */
+int rt_present_async(rt_ctx *ctx, uint8_t *host_bgra, size_t n_bytes, uint32_t *ticket);
+int rt_present_wait(rt_ctx *ctx, uint32_t ticket);
 
 /* Device-side access for callers that keep results on the GPU (multi-GPU combine with RCCL):
  * pointers into the context's own buffers, valid until the next rt_set_view with a different

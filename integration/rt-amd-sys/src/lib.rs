@@ -123,6 +123,10 @@ extern "C" {
     pub fn rt_resolve_accumulation(ctx: *mut rt_ctx, total_samples: u32) -> c_int;
     /// Bgra8UnormSrgb encode of any host RGBA f32 frame through the device kernel (exact bytes).
     pub fn rt_encode_bgra8_srgb(ctx: *mut rt_ctx, rgba: *const f32, n_pixels: usize, bgra: *mut u8) -> c_int;
+    /// Presentation that does not stall frames in flight: encode + copy of the frame rendered last on its own stream;
+    /// `ticket` names the frame's set, `rt_present_wait` blocks until the bytes have arrived in `host_bgra`.
+    pub fn rt_present_async(ctx: *mut rt_ctx, host_bgra: *mut u8, n_bytes: usize, ticket: *mut u32) -> c_int;
+    pub fn rt_present_wait(ctx: *mut rt_ctx, ticket: u32) -> c_int;
     /// Multi-GPU tile exchange: packed size of the largest rank's tiles, pack own tiles, scatter peers' tiles.
     pub fn rt_tile_slot_bytes(ctx: *mut rt_ctx, shard_count: u32, tile_size: u32, bytes: *mut usize) -> c_int;
     pub fn rt_pack_tiles(ctx: *mut rt_ctx, shard_rank: u32, shard_count: u32, tile_size: u32, d_packed: *mut c_void, bytes: usize) -> c_int;

@@ -80,7 +80,7 @@ class EntityView(C.Structure):
 RT_SYMBOLS = ["rt_create", "rt_destroy", "rt_set_stream", "rt_set_frames_in_flight", "rt_get_stream", "rt_upload_scene", "rt_upload_scene_ex", "rt_update_vertices", "rt_update_vertex_range", "rt_host_bvh_refit", "rt_set_view", "rt_render",
               "rt_synchronize", "rt_read_radiance", "rt_read_prim_ids", "rt_read_hit_t", "rt_read_bgra8_srgb",
               "rt_read_accumulation", "rt_device_buffers", "rt_resolve_accumulation", "rt_get_counters",
-              "rt_encode_bgra8_srgb", "rt_tile_slot_bytes", "rt_pack_tiles", "rt_unpack_tiles", "rt_render_static",
+              "rt_encode_bgra8_srgb", "rt_present_async", "rt_present_wait", "rt_tile_slot_bytes", "rt_pack_tiles", "rt_unpack_tiles", "rt_render_static",
               "rt_get_bvh_info", "rt_read_bvh", "rt_read_bvh_wide", "rt_host_bvh_build", "rt_host_bvh_copy", "rt_host_bvh_wide", "rt_host_bvh_free", "rt_last_error", "rt_status_string", "rt_version"]
 RTH_SYMBOLS = ["rth_app_create", "rth_app_destroy", "rth_app_finish", "rth_app_update", "rth_app_ctx",
                "rth_last_error", "rth_add_mesh", "rth_add_cuboid", "rth_add_plane", "rth_add_icosphere",
@@ -127,6 +127,7 @@ def lib():
         "rt_device_buffers": (i, [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]),
         "rt_resolve_accumulation": (i, [vp, u32]),
         "rt_encode_bgra8_srgb": (i, [vp, vp, sz, vp]),
+        "rt_present_async": (i, [vp, vp, sz, vp]), "rt_present_wait": (i, [vp, C.c_uint32]),
         "rt_tile_slot_bytes": (i, [vp, u32, u32, C.POINTER(sz)]),
         "rt_pack_tiles": (i, [vp, u32, u32, u32, vp, sz]),
         "rt_unpack_tiles": (i, [vp, u32, u32, u32, u32, vp, sz]),
@@ -412,6 +413,17 @@ class Context:
 
     def read_bgra8_srgb(self):
         return self._read(lib().rt_read_bgra8_srgb, np.uint8, (self.height, self.width, 4))
+
+    def present_async(self, host_bgra):
+        """rt_present_async: encode + copy of the frame rendered last into `host_bgra` (uint8, H*W*4, C-contiguous; the
+        caller keeps it alive and untouched until present_wait(ticket)), on that frame's stream; returns the ticket."""
+        assert host_bgra.dtype == np.uint8 and host_bgra.flags["C_CONTIGUOUS"]
+        t = C.c_uint32()
+        self._chk(lib().rt_present_async(self._h, host_bgra.ctypes.data, host_bgra.size, C.byref(t)))
+        return t.value
+
+    def present_wait(self, ticket):
+        self._chk(lib().rt_present_wait(self._h, ticket))
 
     def device_buffers(self):
         r, p, a = C.c_void_p(), C.c_void_p(), C.c_void_p()

@@ -46,6 +46,9 @@ struct FrameSet {
     float *d_contrib = nullptr;
     uint32_t contrib_planes = 0;
     float *d_hits = nullptr;              // one 16-B hit record per queued path (k_path_trace -> k_path_shade)
+    uint8_t *d_bgra = nullptr;            // rt_present_async: this set's encoded frame
+    hipEvent_t ev_present = nullptr;      // ... and the arrival of its copy on the host
+    bool present_pending = false;
 };
 #define RT_PATH_SETS 2u
 
@@ -196,6 +199,8 @@ void free_frame(rt_ctx *c) {
         f.q_capacity = 0;
         p = f.d_contrib; free_dev(p); f.d_contrib = nullptr; f.contrib_planes = 0;
         p = f.d_hits; free_dev(p); f.d_hits = nullptr;
+        p = f.d_bgra; free_dev(p); f.d_bgra = nullptr;
+        f.present_pending = false;
     }
     c->n_px = 0;
 }
@@ -351,6 +356,7 @@ int rt_destroy(rt_ctx *c) {
     for (FrameSet &f : c->fs) {
         if (f.own_stream) (void)hipStreamDestroy(f.own_stream);
         if (f.flight_stream) (void)hipStreamDestroy(f.flight_stream);
+        if (f.ev_present) (void)hipEventDestroy(f.ev_present);
     }
     delete c;
     return RT_OK;
@@ -1289,6 +1295,31 @@ int rt_encode_bgra8_srgb(rt_ctx *c, const float *rgba, size_t n_pixels, uint8_t 
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     free_dev(d_in); free_dev(d_out);
     if (e != hipSuccess) return fail(c, e == hipErrorOutOfMemory ? RT_ERR_OOM : RT_ERR_HIP, "rt_encode_bgra8_srgb", e);
+    return RT_OK;
+}
+
+int rt_present_async(rt_ctx *c, uint8_t *host_bgra, size_t n_bytes, uint32_t *ticket) {
+    if (!c || !host_bgra || !ticket) return RT_ERR_ARG;
+    if (!c->has_view || !c->d_rgba) return RT_NOT_READY;
+    if (n_bytes != c->n_px * 4) return fail(c, RT_ERR_ARG, "rt_present_async: size must be W*H*4 bytes");
+    HIPCHK(c, hipSetDevice(c->device));
+    FrameSet &F = c->fs[c->cur_set];
+    if (!F.d_bgra) HIPCHK(c, hipMalloc((void **)&F.d_bgra, c->n_px * 4));
+    if (!F.ev_present) HIPCHK(c, hipEventCreateWithFlags(&F.ev_present, hipEventDisableTiming));
+    HIPCHK(c, rtk_launch_encode_bgra8(c->stream, c->d_rgba, F.d_bgra, c->n_px));
+    HIPCHK(c, hipMemcpyAsync(host_bgra, F.d_bgra, c->n_px * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipEventRecord(F.ev_present, c->stream));
+    F.present_pending = true;
+    *ticket = c->cur_set;
+    return RT_OK;
+}
+
+int rt_present_wait(rt_ctx *c, uint32_t ticket) {
+    if (!c) return RT_ERR_ARG;
+    if (ticket >= RT_MAX_IN_FLIGHT || !c->fs[ticket].present_pending) return fail(c, RT_ERR_ARG, "rt_present_wait: no presentation pending under this ticket");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipEventSynchronize(c->fs[ticket].ev_present));
+    c->fs[ticket].present_pending = false;
     return RT_OK;
 }
 

@@ -349,7 +349,52 @@ def test_get_stream_and_tile_exchange_with_frames_in_flight():
         assert ctx.get_stream() == own                            # one frame at a time: the context's ordinary stream again
 
 
-@pytest.mark.parametrize("env", [{"RT_TUNE_POOL_DEP": "16"}, {"RT_TUNE_POOL_DEP": "24", "RT_TUNE_POOL_PICK": "8", "RT_TUNE_POOL_DRAIN": "1"},
+@pytest.mark.parametrize("n", [1, 3])
+def test_present_async_delivers_the_bytes_of_each_frame_in_flight(n):
+    """rt_present_async / rt_present_wait: the Bgra8UnormSrgb bytes of the frame rendered last, encoded and copied on that
+    frame's stream while the next frames render.  Every ticket's bytes must be those rt_read_bgra8_srgb gives for the same
+    frame (and so the oracle's, byte for byte), into pinned and into pageable host memory, with up to n tickets open."""
+    import torch
+    app = default_app(320, 180)
+    scene = app.prepare_meshinfo()
+    cams = []
+    for k in range(5):
+        app.camera_look_at((9.0 * np.cos(k), 4.0 + k, 9.0 * np.sin(k)), (0, 1, 0), (0, 1, 0))
+        cams.append(app.camera_view())
+    with rt.Context(0) as ctx:
+        ctx.upload_scene(scene)
+        want = []
+        for m, p in cams:
+            ctx.set_view(m, p, 320, 180)
+            ctx.render(flags=rt.FLAG_SHADOW)
+            want.append(ctx.read_bgra8_srgb())
+            assert np.array_equal(want[-1], orc.encode_bgra8_srgb(ctx.read_radiance()))
+            assert want[-1][..., :3].max() > 0
+        ctx.set_frames_in_flight(n)
+        pinned = [torch.empty(180 * 320 * 4, dtype=torch.uint8).pin_memory().numpy().reshape(180, 320, 4) for _ in range(n)]
+        with pytest.raises(rt.RtError):
+            ctx.present_wait(0)                                  # nothing pending yet
+        with pytest.raises(rt.RtError):
+            ctx.present_async(np.empty(16, dtype=np.uint8))      # wrong size
+        open_tickets = []                                         # (ticket, buffer, frame index)
+        for k in range(3 * len(cams)):
+            m, p = cams[k % len(cams)]
+            ctx.set_view(m, p, 320, 180)
+            ctx.render(flags=rt.FLAG_SHADOW)
+            if len(open_tickets) == n:                            # this frame's set is about to be presented again: collect it first
+                t, buf, j = open_tickets.pop(0)
+                ctx.present_wait(t)
+                assert np.array_equal(buf, want[j]), (k, t)
+            buf = pinned[k % n] if k % 2 == 0 else np.empty((180, 320, 4), dtype=np.uint8)
+            buf[...] = 0x5A
+            open_tickets.append((ctx.present_async(buf), buf, k % len(cams)))
+        for t, buf, j in open_tickets:
+            ctx.present_wait(t)
+            assert np.array_equal(buf, want[j])
+        assert len({t for t, _, _ in open_tickets}) == n
+
+
+@pytest.mark.parametrize("env", [{"RT_TUNE_POOL_DEP": "16"},{"RT_TUNE_POOL_DEP": "24", "RT_TUNE_POOL_PICK": "8", "RT_TUNE_POOL_DRAIN": "1"},
                                  {"RT_TUNE_PATH_SPLIT": "1", "RT_TUNE_PATH_REFILL_MIN": "16"}, {"RT_TUNE_PATH_SPLIT": "1", "RT_TUNE_PATH_REFILL_MIN": "1"},
                                  {"RT_TUNE_PATH_SORT": "1"}, {"RT_TUNE_PATH_SORT": "6", "RT_TUNE_PATH_SORT_KEY": "1"}])
 def test_measured_opt_in_variants_stay_bit_identical(env, monkeypatch):

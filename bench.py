@@ -368,7 +368,9 @@ def main():
                 pmc["quoted"] = True
                 traffic = tj.get("hbm_bytes_per_launch")
                 valu = {"busy": tj["valu_busy"], "lanes_active": tj["valu_lanes_active"],
-                        "frac": round(tj["valu_busy"] * tj["valu_lanes_active"], 4)}
+                        "frac": round(tj["valu_busy"] * tj["valu_lanes_active"], 4),
+                        "busy_is": "VALU wave-instructions per second and SIMD over the issue rate profiles/calib/valu_mask reaches (one per ~2.5 cycles)",
+                        "wave_time": tj.get("wave_time"), "waves_per_simd_avg": tj.get("waves_per_simd_avg")}
                 # counters are collected with launches serialised (rocprofv3 --pmc always does): HBM bytes per launch over
                 # the UNOVERLAPPED launch duration
                 if traffic and kernel_ms > 0:
@@ -378,9 +380,10 @@ def main():
             pmc["why"] = f"no usable profiles/pmc_traffic.json: {str(ex)[:80]}"
         # The bound: SURVEY 8d names HBM as the nominal roofline and `achieved`/`frac` keep that definition (ALGORITHMIC
         # bytes -- every lane's node / record fetch, most of them served by L1 / L2 / Infinity Cache -- over kernel time),
-        # but the counters decide the label: VALU issue when the VALU pipes are busier than the memory side.
+        # but the counters decide the label: a pipe that is >= 0.75 busy names the bound; when neither the VALU nor HBM is,
+        # the launch is bound by the LATENCY of its dependent gathers (waves parked at s_waitcnt, wave_time.waiting_for_memory).
         if valu is not None and hbm_frac is not None:
-            bound = "valu" if valu["busy"] > hbm_frac else "hbm"
+            bound = "valu" if valu["busy"] >= 0.75 and valu["busy"] > hbm_frac else ("hbm" if hbm_frac >= 0.75 else "latency")
         else:
             bound = "hbm (nominal; no current counters)"
         out = {

@@ -30,6 +30,7 @@ for f in glob.glob(os.path.join(root, "*", "**", "*_kernel_trace.csv"), recursiv
     for r in csv.DictReader(open(f)):
         if kern in r["Kernel_Name"]:
             dur.append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+VALU_PEAK = 0.909e9      # profiles/calib/valu_mask on this pool: 1.127 ms for 2000 x 64 x 8 FMAs per SIMD (gpurun_out -> profiles/r2/valu_issue_calib.txt)
 simd_cycles = c["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0        # the counter sums the 8 XCDs; 256 CUs x 4 SIMDs
 out = {
     "workload": workload, "kernel": kern,
@@ -38,7 +39,20 @@ out = {
     "fetch_correction": 1.0,
     "correction_basis": "profiles/calib/gather_calib.hip (round 1, same pool): 64-B node / 48-B record gathers read FETCH_SIZE = bytes (factor 1.0); a 16-B/lane coalesced stream would need the guide's factor 2",
     "hbm_bytes_per_launch": int((c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0),
-    "valu_busy": round(c["SQ_ACTIVE_INST_VALU"] * 4.0 / simd_cycles, 3),
+    # VALU issue against the SIMD's MEASURED capacity: profiles/calib/valu_mask (8 waves per SIMD, independent FMAs) retires
+    # VALU_PEAK wave64 instructions per second and SIMD -- one per ~2.5 cycles: a SIMD-32 data path, two waves' 4-cycle issue
+    # slots interleaved (MI355X guide, row 'v_fma_f32 (wave64)').  Rounds 1 and early 2 charged 4 cycles per instruction and
+    # called the kernel VALU-bound at 0.91; that figure is the share of cycles in which SOME wave held an issue slot
+    # (valu_issue_slots, capacity ~1.5 concurrent slots), not the pipe's utilisation.
+    "valu_busy": round(c["SQ_INSTS_VALU"] / 1024.0 / (sum(dur) / len(dur) * 1e-9) / VALU_PEAK, 3) if dur else None,
+    "valu_peak_wave_insts_per_s_per_simd": VALU_PEAK,
+    "valu_issue_slots": round(c["SQ_ACTIVE_INST_VALU"] * 4.0 / simd_cycles, 3),
+    # where a resident wave's time goes (SQ_WAIT_ANY: parked at s_waitcnt, i.e. on memory; SQ_WAIT_INST_ANY: ready but not
+    # issued; SQ_ACTIVE_INST_ANY: issuing), and how many waves a SIMD holds on average over the launch
+    "wave_time": {"waiting_for_memory": round(c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"], 3),
+                  "issue_stalled": round(c["SQ_WAIT_INST_ANY"] / c["SQ_WAVE_CYCLES"], 3),
+                  "issuing": round(c["SQ_ACTIVE_INST_ANY"] / c["SQ_WAVE_CYCLES"], 3)} if "SQ_WAIT_ANY" in c else None,
+    "waves_per_simd_avg": round(c["SQ_WAVE_CYCLES"] * 4.0 / simd_cycles, 2) if "SQ_WAVE_CYCLES" in c else None,
     "valu_lanes_active": round(c["SQ_THREAD_CYCLES_VALU"] / (64.0 * c["SQ_ACTIVE_INST_VALU"]), 3),
     "valu_insts_per_launch": int(c["SQ_INSTS_VALU"]),
     "ta_busy": round(c["TA_BUSY_avr"] / (c["GRBM_GUI_ACTIVE"] / 8.0), 3) if "TA_BUSY_avr" in c else None,

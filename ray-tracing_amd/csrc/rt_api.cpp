@@ -72,6 +72,7 @@ struct rt_ctx {
     std::vector<rt_triangle> h_tris;      // topology of the uploaded scene
     std::vector<rt_mesh_info> h_meshes;
     std::vector<uint32_t> h_mesh_vlo, h_mesh_vhi;   // per mesh: lowest / highest vertex index its triangles use
+    std::vector<uint8_t> h_vert_used;     // per vertex: some triangle of the scene uses it
     void *d_dirty = nullptr;              // one byte per binary node (rt_update_vertex_range)
     // rt_update_vertex_range, short-list form (topology only: valid through refits): parent and depth of every binary
     // node, the wide node its two boxes are slots of, per mesh the nodes that hold one of its records in a leaf child
@@ -633,6 +634,8 @@ int rt_upload_scene_ex(rt_ctx *c, const rt_triangle *tris, size_t n_tris, const 
     c->h_tris.assign(tris, tris + n_tris);
     c->h_meshes.assign(meshes, meshes + n_meshes);
     c->h_mesh_vlo.assign(n_meshes, 0xFFFFFFFFu); c->h_mesh_vhi.assign(n_meshes, 0u);
+    c->h_vert_used.assign(n_verts, 0);
+    for (size_t t = 0; t < n_tris; ++t) for (int k = 0; k < 3; ++k) c->h_vert_used[tris[t].indices[k]] = 1;
     for (size_t m = 0; m < n_meshes; ++m)
         for (uint32_t t = meshes[m].first_tri; t < meshes[m].first_tri + meshes[m].tri_count; ++t)
             for (int k = 0; k < 3; ++k) {
@@ -719,9 +722,8 @@ int rt_update_vertices(rt_ctx *c, const rt_vertex *verts, size_t n_verts, const 
         // up front (the tree would have to drop that triangle), before anything on the device changes.
         for (size_t i = 0; i < n_verts; ++i)
             if (!std::isfinite(verts[i].pos[0]) || !std::isfinite(verts[i].pos[1]) || !std::isfinite(verts[i].pos[2])) {
-                bool used = false;   // only vertices some triangle of the tree uses matter (as in the host refit)
-                for (const rt_triangle &T : c->h_tris) if (T.indices[0] == i || T.indices[1] == i || T.indices[2] == i) { used = true; break; }
-                if (used) return fail(c, RT_ERR_SCENE, "rt_update_vertices: non-finite vertex, rebuild with rt_upload_scene");
+                // only vertices some triangle of the scene uses matter (as in the host refit)
+                if (i < c->h_vert_used.size() && c->h_vert_used[i]) return fail(c, RT_ERR_SCENE, "rt_update_vertices: non-finite vertex, rebuild with rt_upload_scene");
             }
         for (hipEvent_t &ev : c->ev_update) if (!ev) HIPCHK(c, hipEventCreate(&ev));
         const hipEvent_t e0 = c->ev_update[0], e1 = c->ev_update[1];

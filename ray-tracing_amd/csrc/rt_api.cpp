@@ -80,7 +80,12 @@ struct rt_ctx {
     std::vector<uint32_t> h_parent, h_depth, h_stamp, h_wide_of_bin, h_mesh_node_off, h_mesh_nodes;
     uint32_t stamp = 0;
     void *d_list = nullptr; size_t list_capacity = 0;
-    uint32_t tune_refit_list_max = 16384;  // RT_TUNE_REFIT_LIST_MAX: longer lists take the per-level launches (0 = always); tools/refit_time.py
+    // the list on the device is kept with the mesh range it was made for: an animation moves the same meshes every frame
+    // (the reference's rotating cube, src/main.rs:122-126), and the tree's topology only changes with rt_upload_scene
+    struct { bool valid = false, level_lists = false; size_t first_mesh = 0, n_meshes = 0; std::vector<uint32_t> level_end; uint32_t n_wide = 0; } list_cache;
+    size_t last_range_first = (size_t)-1, last_range_n = 0;   // the mesh range of the call before this one
+    uint32_t tune_refit_list_max = 16384;  // RT_TUNE_REFIT_LIST_MAX: lists up to this many nodes are redone by ONE launch of one workgroup (0 = never); tools/refit_time.py
+    uint32_t tune_refit_levels_max = 262144;   // RT_TUNE_REFIT_LEVELS_MAX: longer lists, up to this, by one launch per tree level over the LISTED nodes; beyond: the whole-tree level launches
     void *d_level_nodes = nullptr;        // node indices grouped by tree level, deepest level first (GPU refit)
     std::vector<uint32_t> level_count;    // nodes per group, in that order
 
@@ -176,6 +181,7 @@ void free_scene(rt_ctx *c) {
     free_dev(c->d_spheres); free_dev(c->d_sphere_mats); free_dev(c->d_level_nodes);
     free_dev(c->d_wide); free_dev(c->d_wide_src); free_dev(c->d_dirty);
     free_dev(c->d_list); c->list_capacity = 0;
+    c->list_cache.valid = false; c->last_range_first = (size_t)-1; c->last_range_n = 0;
     c->level_count.clear();
     c->has_scene = false;
     std::memset(&c->S, 0, sizeof c->S);
@@ -304,6 +310,7 @@ int rt_create(int device_ordinal, rt_ctx **out) {
         c->tune.refill_min = env("RT_TUNE_REFILL_MIN", 64, 1, 64);
         c->tune.finish_min = env("RT_TUNE_FINISH_MIN", 64, 1, 64);
         c->tune_refit_list_max = (uint32_t)env("RT_TUNE_REFIT_LIST_MAX", 16384, 0, 1 << 24);
+        c->tune_refit_levels_max = (uint32_t)env("RT_TUNE_REFIT_LEVELS_MAX", 262144, 0, 1 << 26);
         c->tune.vote_node = env("RT_TUNE_VOTE_NODE", 3, 1, 64);
         c->tune.vote_tri = env("RT_TUNE_VOTE_TRI", 1, 1, 64);
         c->tune.uni_min = env("RT_TUNE_UNI_MIN", 16, 1, 65);
@@ -796,12 +803,27 @@ int rt_update_vertex_range(rt_ctx *c, const rt_vertex *verts, size_t first_verte
     HIPCHK(c, sync_all(c));          // frames in flight on other sets still walk the tree this call rewrites
     const size_t nn = c->S.n_nodes;
     // Which nodes have a moved mesh below them: walked on the host's copy of the topology (mesh-id spans per node), a few
-    // thousand nodes for a mesh of a few hundred triangles.  A short list is redone by ONE launch (k_refit_list); a long
-    // one by the per-level launches over the whole tree with a dirty byte per node.
+    // thousand nodes for a mesh of a few hundred triangles.  A short list is redone by ONE launch of one workgroup
+    // (k_refit_list); a medium one -- tens to hundreds of meshes -- by one launch per tree level over the LISTED nodes of that
+    // level (by_level_lists); a long one by the per-level launches over the whole tree with a dirty byte per node.
+    // Making a long list costs the host more than the whole-tree launches cost the device (climbing 55,000 nodes for 50
+    // spheres: 1 ms of cache misses), so a long list is made only when the call before this one named the same meshes -- an
+    // animation -- and then kept on the device: every further frame of it pays the launches alone.
     std::vector<uint32_t> list, level_end;
     uint32_t n_wide_listed = 0;
-    bool by_list = false;
-    if (nn && n_meshes && c->tune_refit_list_max && c->h_parent.size() == nn) {
+    bool by_list = false, by_level_lists = false, cached = false;
+    const size_t list_limit = std::max(c->tune_refit_list_max, c->tune_refit_levels_max);
+    const bool repeated = c->last_range_first == first_mesh && c->last_range_n == n_meshes;
+    c->last_range_first = first_mesh; c->last_range_n = n_meshes;
+    // leaf-holding nodes of the moved meshes (CSR offsets): the list is about three times as long
+    const size_t est = nn && n_meshes && c->h_mesh_node_off.size() > first_mesh + n_meshes ?
+                       3 * (size_t)(c->h_mesh_node_off[first_mesh + n_meshes] - c->h_mesh_node_off[first_mesh]) : 0;
+    if (c->list_cache.valid && c->list_cache.first_mesh == first_mesh && c->list_cache.n_meshes == n_meshes) {
+        cached = by_list = true;
+        by_level_lists = c->list_cache.level_lists;
+        level_end = c->list_cache.level_end;
+        n_wide_listed = c->list_cache.n_wide;
+    } else if (nn && n_meshes && list_limit && c->h_parent.size() == nn && (est <= c->tune_refit_list_max || repeated)) {
         std::vector<std::vector<uint32_t>> per_level;
         size_t total = 0;
         by_list = true;
@@ -811,10 +833,11 @@ int rt_update_vertex_range(rt_ctx *c, const rt_vertex *verts, size_t first_verte
                 for (uint32_t n = c->h_mesh_nodes[q]; n != 0xFFFFFFFFu && c->h_stamp[n] != c->stamp; n = c->h_parent[n]) {   // up to the first node already listed
                     c->h_stamp[n] = c->stamp;
                     const uint32_t d = c->h_depth[n];
-                    if (++total > c->tune_refit_list_max || d + 1 >= RT_REFIT_LIST_MAX_LEVELS) { by_list = false; break; }
+                    if (++total > list_limit || d + 1 >= RT_REFIT_LIST_MAX_LEVELS) { by_list = false; break; }
                     if (per_level.size() <= d) per_level.resize(d + 1);
                     per_level[d].push_back(n);
                 }
+        by_level_lists = by_list && total > c->tune_refit_list_max;
         if (by_list) {
             for (size_t d = per_level.size(); d-- > 0;) {           // deepest level first
                 list.insert(list.end(), per_level[d].begin(), per_level[d].end());
@@ -830,6 +853,7 @@ int rt_update_vertex_range(rt_ctx *c, const rt_vertex *verts, size_t first_verte
                 n_wide_listed = (uint32_t)w.size();
                 list.insert(list.end(), w.begin(), w.end());
             }
+            c->list_cache.valid = false;                            // d_list is about to hold another list
             if (list.size() > c->list_capacity) {
                 HIPCHK(c, hipStreamSynchronize(c->stream));
                 free_dev(c->d_list); c->list_capacity = 0;
@@ -844,9 +868,18 @@ int rt_update_vertex_range(rt_ctx *c, const rt_vertex *verts, size_t first_verte
     const hipEvent_t e0 = c->ev_update[0], e1 = c->ev_update[1];
     if (n_verts) HIPCHK(c, hipMemcpyAsync((rt_vertex *)c->d_verts + first_vertex, verts, n_verts * sizeof(rt_vertex), hipMemcpyHostToDevice, c->stream));
     if (n_meshes) HIPCHK(c, hipMemcpyAsync((rt_mesh_info *)c->d_meshes + first_mesh, meshes, n_meshes * sizeof(rt_mesh_info), hipMemcpyHostToDevice, c->stream));
-    if (by_list && !list.empty()) HIPCHK(c, hipMemcpyAsync(c->d_list, list.data(), list.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+    if (by_list && !cached && !list.empty()) HIPCHK(c, hipMemcpyAsync(c->d_list, list.data(), list.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipEventRecord(e0, c->stream));
-    if (by_list) {
+    if (by_level_lists) {
+        uint32_t begin = 0;
+        for (uint32_t end : level_end) {                            // a launch per level, over that level's listed nodes only
+            HIPCHK(c, rtk_launch_refit_level(c->stream, (RtBvhNode *)c->d_nodes, (RtTriRecord *)c->d_recs, (const rt_triangle *)c->d_tris,
+                                             (const rt_vertex *)c->d_verts, (const uint32_t *)c->d_list + begin, end - begin));
+            begin = end;
+        }
+        HIPCHK(c, rtk_launch_wide_requant_list(c->stream, (const RtBvhNode *)c->d_nodes, (const RtWideSrc *)c->d_wide_src, (RtWideNode *)c->d_wide,
+                                               (const uint32_t *)c->d_list + begin, n_wide_listed));
+    } else if (by_list) {
         if (!level_end.empty())
             HIPCHK(c, rtk_launch_refit_list(c->stream, (RtBvhNode *)c->d_nodes, (RtTriRecord *)c->d_recs, (const rt_triangle *)c->d_tris,
                                             (const rt_vertex *)c->d_verts, (const uint32_t *)c->d_list, level_end.data(), (uint32_t)level_end.size(),
@@ -868,6 +901,11 @@ int rt_update_vertex_range(rt_ctx *c, const rt_vertex *verts, size_t first_verte
     float ms = 0.0f;
     HIPCHK(c, hipEventElapsedTime(&ms, e0, e1));
     c->bvh_host_stale = true;
+    if (by_list && !cached && !list.empty()) {       // the list has arrived (the stream was synchronised): good for the next call with this range
+        c->list_cache.valid = true; c->list_cache.level_lists = by_level_lists;
+        c->list_cache.first_mesh = first_mesh; c->list_cache.n_meshes = n_meshes;
+        c->list_cache.level_end = level_end; c->list_cache.n_wide = n_wide_listed;
+    }
     // out of the wide step's coordinate range: binary tree until a full update or upload shows everything is back in
     if (!(amax * 1.0001f < RT_WIDE_COORD_MAX)) c->S.n_wide = 0;
     for (size_t m = 0; m < n_meshes; ++m) c->h_meshes[first_mesh + m] = meshes[m];

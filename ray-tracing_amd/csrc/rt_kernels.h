@@ -71,6 +71,9 @@ hipError_t rtk_launch_refit_level_dirty(hipStream_t st, RtBvhNode *nodes, RtTriR
 hipError_t rtk_launch_wide_requant_dirty(hipStream_t st, const RtBvhNode *nodes, const RtWideSrc *src, RtWideNode *wide,
                                          uint32_t n, const uint8_t *dirty);
 
+// the wide nodes named in list[0..n) re-quantised (the medium-sized update of rt_update_vertex_range)
+hipError_t rtk_launch_wide_requant_list(hipStream_t st, const RtBvhNode *nodes, const RtWideSrc *src, RtWideNode *wide, const uint32_t *list, uint32_t n);
+
 // after a refit: every wide node's child boxes re-quantised from the binary tree's boxes (rt_wide.h)
 hipError_t rtk_launch_wide_requant(hipStream_t st, const RtBvhNode *nodes, const RtWideSrc *src, RtWideNode *wide, uint32_t n);
 

@@ -1678,6 +1678,20 @@ hipError_t rtk_launch_wide_requant_dirty(hipStream_t st, const RtBvhNode *nodes,
     hipLaunchKernelGGL(k_wide_requant_dirty, dim3((n + 255) / 256), dim3(256), 0, st, nodes, src, wide, n, dirty);
     return hipGetLastError();
 }
+__global__ void k_wide_requant_list(const RtBvhNode *__restrict__ nodes, const RtWideSrc *__restrict__ src, RtWideNode *wide,
+                                    const uint32_t *__restrict__ list, uint32_t n) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t w = list[i];
+    RtWideNode W = wide[w];
+    rt_wide_quantise(nodes, src[w], W);
+    wide[w] = W;
+}
+hipError_t rtk_launch_wide_requant_list(hipStream_t st, const RtBvhNode *nodes, const RtWideSrc *src, RtWideNode *wide, const uint32_t *list, uint32_t n) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_wide_requant_list, dim3((n + 255) / 256), dim3(256), 0, st, nodes, src, wide, list, n);
+    return hipGetLastError();
+}
 hipError_t rtk_launch_wide_requant(hipStream_t st, const RtBvhNode *nodes, const RtWideSrc *src, RtWideNode *wide, uint32_t n) {
     if (n == 0) return hipSuccess;
     hipLaunchKernelGGL(k_wide_requant, dim3((n + 255) / 256), dim3(256), 0, st, nodes, src, wide, n);

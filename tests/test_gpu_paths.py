@@ -421,13 +421,16 @@ def test_wide_tree_conservative_culling_at_the_extremes(case):
         ctx.close()
 
 
-@pytest.mark.parametrize("list_max", ["16384", "0", "700"])
-def test_update_vertex_range_refits_only_the_moved_meshes(list_max, monkeypatch):
+@pytest.mark.parametrize("list_max,levels_max", [("16384", "262144"), ("0", "0"), ("700", "262144"), ("0", "262144"), ("700", "0")])
+def test_update_vertex_range_refits_only_the_moved_meshes(list_max, levels_max, monkeypatch):
     """f1, dirty-mesh form: four of thirty spheres move; only their vertices are sent, only their leaves re-baked and only
     their ancestors refitted -- and the tree (binary and wide) is the one a full rt_update_vertices leaves, bit for bit.
-    Both forms of the device side: one launch over a host-made list of the nodes above the moved meshes (default), and
-    the per-level launches with a dirty byte per node (RT_TUNE_REFIT_LIST_MAX=0, or a list longer than the limit)."""
+    All three forms of the device side: one launch of one workgroup over a host-made list of the nodes above the moved
+    meshes (default for short lists), one launch per tree level over that list's nodes of the level (lists beyond
+    RT_TUNE_REFIT_LIST_MAX, up to RT_TUNE_REFIT_LEVELS_MAX), and the per-level launches over the whole tree with a dirty
+    byte per node (beyond both limits)."""
     monkeypatch.setenv("RT_TUNE_REFIT_LIST_MAX", list_max)
+    monkeypatch.setenv("RT_TUNE_REFIT_LEVELS_MAX", levels_max)
     app = soup_app(30, 0x5EED0003, 160, 90, subdivisions=3)
     app.camera_frame_scene(1.0)
     scene = app.prepare_meshinfo()
@@ -460,9 +463,29 @@ def test_update_vertex_range_refits_only_the_moved_meshes(list_max, monkeypatch)
         nodes_p, recs_p = part.read_bvh()
         assert bitwise_equal(nodes_p, nodes_f) and bitwise_equal(recs_p, recs_f)
         assert bitwise_equal(part.read_bvh_wide(), full.read_bvh_wide())
-        # a second, different move of the same meshes, then back: still the full update's tree
+        # a second, different move of the same meshes, then back: still the full update's tree.  The same range again is
+        # what an animation does: a long list is made on the first repeat (until then the whole-tree launches serve) and
+        # every list is kept on the device for the calls that follow
         part.update_vertex_range(scene, v_lo, v_hi - v_lo + 1, m0, m1 - m0)
         full.update_vertices(scene)
+        assert bitwise_equal(part.read_bvh()[0], full.read_bvh()[0]) and bitwise_equal(part.read_bvh_wide(), full.read_bvh_wide())
+        for pose in (moved, scene, moved):
+            part.update_vertex_range(pose, v_lo, v_hi - v_lo + 1, m0, m1 - m0)
+            full.update_vertices(pose)
+            assert bitwise_equal(part.read_bvh()[0], full.read_bvh()[0]) and bitwise_equal(part.read_bvh()[1], full.read_bvh()[1])
+            assert bitwise_equal(part.read_bvh_wide(), full.read_bvh_wide())
+        # another range in between replaces the kept list; back on the first range a new one is made
+        other = rt.Scene(scene.triangles, moved.meshes.copy(), moved.vertices.copy(), scene.materials)
+        mo = other.meshes[20]
+        vo = np.unique(other.triangles["indices"][mo["first_tri"]:mo["first_tri"] + mo["tri_count"]])
+        other.vertices["pos"][vo] += np.float32(0.5); other.meshes["aabb_min"][20] += np.float32(0.5); other.meshes["aabb_max"][20] += np.float32(0.5)
+        for _ in range(2):
+            part.update_vertex_range(other, int(vo.min()), int(vo.max() - vo.min() + 1), 20, 1)
+        part.update_vertex_range(other, v_lo, v_hi - v_lo + 1, m0, m1 - m0)
+        full.update_vertices(other)
+        assert bitwise_equal(part.read_bvh()[0], full.read_bvh()[0]) and bitwise_equal(part.read_bvh_wide(), full.read_bvh_wide())
+        part.update_vertex_range(moved, int(vo.min()), int(vo.max() - vo.min() + 1), 20, 1)
+        full.update_vertices(moved)
         assert bitwise_equal(part.read_bvh()[0], full.read_bvh()[0]) and bitwise_equal(part.read_bvh_wide(), full.read_bvh_wide())
         # the range must hold exactly the moved meshes' vertices
         with pytest.raises(rt.RtError) as e:
@@ -775,11 +798,12 @@ def test_deep_tree_uses_the_private_part_of_the_stack():
             assert ctx.counters().tri_tests > 10_000                         # they walked into the stack, leaf after leaf
 
 
-@pytest.mark.parametrize("list_max", ["16384", "0"])
-def test_update_vertex_range_random_sequences(list_max, monkeypatch):
+@pytest.mark.parametrize("list_max,levels_max", [("16384", "262144"), ("0", "0"), ("0", "262144")])
+def test_update_vertex_range_random_sequences(list_max, levels_max, monkeypatch):
     """A sequence of random ranged updates (runs of 1-6 meshes, random moves, some back to where they were) on one context
     against full updates on another: after every step the binary tree, the records and the wide tree must be identical."""
     monkeypatch.setenv("RT_TUNE_REFIT_LIST_MAX", list_max)
+    monkeypatch.setenv("RT_TUNE_REFIT_LEVELS_MAX", levels_max)
     app = soup_app(40, 0x5EED0007, 96, 54, subdivisions=2)
     app.camera_frame_scene(1.0)
     scene = app.prepare_meshinfo()

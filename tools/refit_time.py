@@ -18,21 +18,23 @@ for rep in range(3):
     t0 = time.perf_counter(); ctx.update_vertex_range(one, int(vs.min()), int(vs.max() - vs.min() + 1), k, 1); dt = time.perf_counter() - t0
     print("range rt_update_vertex_range (1 of 10,000 spheres, %d vertices) wall %.2f ms, device %.2f ms" % (len(vs), dt * 1e3, ctx.bvh_info().build_ms), flush=True)
 ctx.render(flags=rt.FLAG_SHADOW); prim_r = ctx.read_prim_ids()
-# more meshes at once, both device forms (one launch over a host-made node list / per-level launches over the whole tree)
-for lim in ("16777216", "0"):
-    os.environ["RT_TUNE_REFIT_LIST_MAX"] = lim
+# more meshes at once, the three device forms: ONE launch of one workgroup over a host-made node list / one launch per tree
+# level over the listed nodes of that level / per-level launches over the whole tree with a dirty byte per node
+for name, lim, lev in (("one workgroup", "16777216", "0"), ("level lists", "0", "67108864"), ("whole tree", "0", "0"), ("defaults", None, None)):
+    for key, val in (("RT_TUNE_REFIT_LIST_MAX", lim), ("RT_TUNE_REFIT_LEVELS_MAX", lev)):
+        if val is None: os.environ.pop(key, None)
+        else: os.environ[key] = val
     cx = rt.Context(0); cx.upload_scene(sc); cx.set_view(m, p, 1920, 1080)
-    for nm in (1, 10, 50, 200):
+    for nm in (1, 10, 50, 200, 1000):
         k0 = 4000
         vlo = int(min(np.min(sc.triangles["indices"][sc.meshes[q]["first_tri"]:sc.meshes[q]["first_tri"] + sc.meshes[q]["tri_count"]]) for q in range(k0, k0 + nm)))
         vhi = int(max(np.max(sc.triangles["indices"][sc.meshes[q]["first_tri"]:sc.meshes[q]["first_tri"] + sc.meshes[q]["tri_count"]]) for q in range(k0, k0 + nm)))
-        best = (1e9, 0)
-        for rep in range(3):
+        calls = []
+        for rep in range(5):     # the same range five times in a row: first call, first repeat (a long list is made now), kept list
             t0 = time.perf_counter(); cx.update_vertex_range(sc, vlo, vhi - vlo + 1, k0, nm); dt = time.perf_counter() - t0
-            best = min(best, (dt * 1e3, cx.bvh_info().build_ms))
-        print("list limit %s: %d meshes (%d vertices): wall %.2f ms, device %.2f ms" % (lim, nm, vhi - vlo + 1, best[0], best[1]), flush=True)
+            calls.append((dt * 1e3, cx.bvh_info().build_ms))
+        print("%-13s: %4d meshes (%d vertices): wall ms by call %s, device %.2f ms" % (name, nm, vhi - vlo + 1, " ".join("%.2f" % w for w, _ in calls), calls[-1][1]), flush=True)
     cx.close()
-os.environ.pop("RT_TUNE_REFIT_LIST_MAX")
 ctx2 = rt.Context(0); ctx2.upload_scene(sc); ctx2.set_view(m, p, 1920, 1080); ctx2.update_vertices(one); ctx2.render(flags=rt.FLAG_SHADOW)
 print("range == full update:", bool((ctx2.read_prim_ids() == prim_r).all()), flush=True)
 ctx.close(); ctx2.close()

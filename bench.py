@@ -405,7 +405,9 @@ def main():
                          "kernel": kernel, "kernel_ms": round(kernel_ms, 4),
                          **({"kernel_ms_is": "launch duration one frame at a time (HIP events around every launch of the pass after the timed region)",
                              "kernel_ms_in_flight": round(kernel_ms_in_flight, 4),
-                             "kernel_ms_in_flight_is": f"the same events in the timed region, {n_in_flight} frames in flight: begin-to-end time of launches that share the GPU"} if overlapped else {}),
+                             "kernel_ms_in_flight_is": f"the same events in the timed region, {n_in_flight} frames in flight: begin-to-end time of launches that share the GPU",
+                             **({"kernel_in_flight": f"k_stream8<false, {'true' if wide else 'false'}>: the same kernel built for 8 waves per SIMD, launched with three or more frames in flight"}
+                                if kernel.startswith("k_stream<") and kernel.endswith("false>") and n_in_flight >= 3 and not os.environ.get("RT_TUNE_STREAM_WAVES") else {})} if overlapped else {}),
                          "algorithmic_bytes_per_launch": int(alg_bytes),
                          "node_visits": int(cnt.node_visits), "tri_tests": int(cnt.tri_tests),
                          "bytes_per_ray": round(alg_bytes / max(rays_step, 1), 1)},

@@ -348,6 +348,7 @@ int rt_create(int device_ordinal, rt_ctx **out) {
         c->tune.pool_dep = env("RT_TUNE_POOL_DEP", 0, 0, 32);
         c->tune.pool_pick = env("RT_TUNE_POOL_PICK", 40, 1, 64);
         c->tune.pool_drain = env("RT_TUNE_POOL_DRAIN", 0, 0, 1);
+        c->tune.stream_waves = env("RT_TUNE_STREAM_WAVES", 0, 0, 8);
         c->tune.path_split = env("RT_TUNE_PATH_SPLIT", 0, 0, 1);
         c->tune.path_refill_min = env("RT_TUNE_PATH_REFILL_MIN", 16, 1, 64);
         c->tune.path_sort = env("RT_TUNE_PATH_SORT", 0, 0, 6);

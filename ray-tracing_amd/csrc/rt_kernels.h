@@ -25,6 +25,7 @@ struct RtTune {
     uint32_t uni_min;          // lanes that must share one node for the scalar node fetch (65 = never)
     uint32_t wide_vote_node, wide_vote_tri;   // the same vote weights when the 4-wide tree is walked
     uint32_t pool_dep, pool_pick, pool_drain;   // k_stream's tail pool: deposit at <= pool_dep unfinished rays (0 = off), pick up at >= pool_pick pooled rays, pool_drain: deposit at the frame's end too
+    uint32_t stream_waves;     // k_stream build: 0 = by frames in flight (8 waves per SIMD with three or more, else 7), 7 or 8 = that one
     uint32_t path_split;       // bounce segments as k_path_trace + k_path_shade (1) or as k_path_bounce (0)
     uint32_t path_sort, path_sort_key;   // k_path_bounce_sorted: 256-path chunks a block regroups by direction (0 = off), key (0 octant, 1 octant x major axis)
     uint32_t path_refill_min;  // k_path_trace: ended rays in a wave that trigger a refill

@@ -1032,6 +1032,16 @@ __global__ __launch_bounds__(RT_BLOCK, POOL ? (RT_STREAM_WAVES < 5 ? RT_STREAM_W
     float *__restrict__ tout, unsigned long long *__restrict__ counters) {
     stream_body<COUNT, WIDE, POOL>(S_, V_, sh_, flags, tn, rgba, prim, tout, counters);
 }
+// The same kernel built for 8 waves per SIMD (64 VGPRs, 10 spilled): launched with three or more frames in flight, where the
+// chip never drains and one more wave per SIMD hides more of the gathers' latency than the spills cost -- bench scene, 4 in
+// flight: 0.597 -> 0.582 ms per frame (1 M-triangle soup 0.394 -> 0.387); one frame at a time it is the same or 2 % slower,
+// and 6 waves are 7 % slower in flight (profiles/r2/ab_waves_in_flight.txt).
+template <bool COUNT, bool WIDE>
+__global__ __launch_bounds__(RT_BLOCK, 8) void k_stream8(
+    RtSceneDev S_, RtViewDev V_, RtShardDev sh_, uint32_t flags, RtStreamTune tn, float4 *__restrict__ rgba, uint32_t *__restrict__ prim,
+    float *__restrict__ tout, unsigned long long *__restrict__ counters) {
+    stream_body<COUNT, WIDE, false>(S_, V_, sh_, flags, tn, rgba, prim, tout, counters);
+}
 
 // ---- A2 RNG: ray_tracing.wgsl:38-74 (integer core; deterministic log/cos) ------------------------
 __device__ __forceinline__ uint32_t next_random(uint32_t &state) {
@@ -1829,7 +1839,10 @@ hipError_t rtk_launch_primary(hipStream_t st, const RtSceneDev &S, const RtViewD
         // frames' blocks and each launch a shorter tail (tools/ab_in_flight_knobs.py, 4 in flight: bench scene 0.603 -> 0.597 ms,
         // 1 M-triangle soup 0.412 -> 0.396; one frame at a time the same setting costs 10 %)
         if (per_cu == 0) per_cu = tree <= ((size_t)4 << 20) ? 3u : (tree <= ((size_t)16 << 20) || tune.frames_in_flight >= 3u ? 5u : 8u);
-        if (per_cu > RT_STREAM_WAVES) per_cu = RT_STREAM_WAVES;      // what a CU can hold: later blocks would only find empty queues
+        // 8 waves per SIMD with frames in flight (k_stream8), else the 7-wave build; tune.stream_waves (7 / 8) overrides for A/Bs
+        const bool eight = tune.pool_dep == 0u && (tune.stream_waves ? tune.stream_waves == 8u : tune.frames_in_flight >= 3u);
+        const uint32_t cu_holds = eight ? 8u : (uint32_t)RT_STREAM_WAVES;
+        if (per_cu > cu_holds) per_cu = cu_holds;      // what a CU can hold: later blocks would only find empty queues
         uint32_t need = (sh.n_owned * sh.tile * sh.tile + RT_BLOCK - 1) / RT_BLOCK;
         uint32_t grid = tune.cus * per_cu < need ? tune.cus * per_cu : need;
         if (grid == 0) return hipSuccess;
@@ -1840,6 +1853,14 @@ hipError_t rtk_launch_primary(hipStream_t st, const RtSceneDev &S, const RtViewD
         tn.pool_dep = tune.pool_dep; tn.pool_pick = tune.pool_pick; tn.pool_drain = tune.pool_drain;
 #define RT_LAUNCH_STREAM(C, W, P) \
     hipLaunchKernelGGL((k_stream<C, W, P>), dim3(grid), dim3(RT_BLOCK), 0, st, S, V, sh, flags, tn, (float4 *)rgba, prim, t, counters)
+#define RT_LAUNCH_STREAM8(C, W) \
+    hipLaunchKernelGGL((k_stream8<C, W>), dim3(grid), dim3(RT_BLOCK), 0, st, S, V, sh, flags, tn, (float4 *)rgba, prim, t, counters)
+        if (eight) {
+            if (count) { if (wide) RT_LAUNCH_STREAM8(true, true); else RT_LAUNCH_STREAM8(true, false); }
+            else { if (wide) RT_LAUNCH_STREAM8(false, true); else RT_LAUNCH_STREAM8(false, false); }
+            return hipGetLastError();
+        }
+#undef RT_LAUNCH_STREAM8
         const int variant = (count ? 4 : 0) | (wide ? 2 : 0) | (tn.pool_dep != 0u ? 1 : 0);
         switch (variant) {
             case 0: RT_LAUNCH_STREAM(false, false, false); break;

@@ -8,7 +8,7 @@ mkdir -p $P
 # the default command minus the extras that run the same kernel on another scene; it holds BOTH kinds of launches (4 frames
 # in flight in the timed region, then one frame at a time): --stats averages over both, tools/trace_phases.py splits them
 timeout -s KILL 200 rocprofv3 --kernel-trace --stats --output-format csv -d $P/stats -- python bench.py --no-cpu-baseline --no-north-star > $P/stats.json 2> $P/stats.log || { tail $P/stats.log; exit 1; }
-python tools/trace_phases.py $P/stats "k_stream<false, true, false>" > $P/kernel_phases.txt || exit 1
+python tools/trace_phases.py $P/stats "k_stream" > $P/kernel_phases.txt || exit 1
 cat $P/kernel_phases.txt
 # and one frame at a time only: every launch alone, --stats' average IS the kernel's duration
 timeout -s KILL 200 rocprofv3 --kernel-trace --stats --output-format csv -d $P/stats_one -- python bench.py --in-flight 1 --no-cpu-baseline --no-pipelined --no-north-star > $P/stats_one.json 2> $P/stats_one.log || { tail $P/stats_one.log; exit 1; }

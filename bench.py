@@ -129,8 +129,8 @@ def self_launch(n):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200)      # 0.12 s of frames: the four-deep pipeline's fill and drain (inside the timed region) weigh 1 %, not 4
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="sphere_field_10k_1080p_primary_shadow", choices=sorted(WORKLOADS))
     ap.add_argument("--mode", default="tiles", choices=["frames", "tiles", "samples"], help="N > 1 only; tiles = north_star's partitioning")
     ap.add_argument("--no-cpu-baseline", action="store_true")

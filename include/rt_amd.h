@@ -185,9 +185,22 @@ int rt_synchronize(rt_ctx *ctx);
  *     that says so.  RT_FLAG_TIME_KERNELS is refused (it creates events).
  *   - calls no hipMalloc / hipFree / hipEventCreate or any other allocating routine, first call included (scene and
  *     view are set up beforehand with rt_upload_scene / rt_set_view, which do allocate).
- * Asynchronous on the context's stream; rt_get_counters then reports this frame.  ALL calls on one GPU share that GPU's
- * array: calls that overlap on one GPU (two contexts, two streams) race -- serialise them.  The array keeps the last
- * call's contents; what must start at zero is cleared by the call itself. */
+ * Asynchronous on ONE stream per context, whatever rt_render did in between: the caller's stream (rt_set_stream) or, on the
+ * context's own streams, the stream of frame set 0 (with frames in flight the context's "frame rendered last" then names set
+ * 0); rt_get_counters then reports this frame.  ALL calls on one GPU share that GPU's array: calls that overlap on one GPU
+ * (two contexts, two streams) race -- serialise them.  The array keeps the last call's contents; what must start at zero is
+ * cleared by the call itself.
+ * Under stream capture (the call recorded into a HIP graph): hand the capturing stream to rt_set_stream BEFORE the capture
+ * begins (rt_set_stream synchronises, which a capture forbids) -- a call on any other stream is simply not recorded.  The
+ * recorded launches hold BY VALUE: the device addresses of the scene's buffers, the view (camera matrix, size, viewport), the
+ * render parameters, the caller's output pointers, the address of the context's pinned counter block and of this GPU's
+ * scratch array.  A replay therefore redoes exactly the recorded frame (rt_update_vertices / rt_update_vertex_range between
+ * replays are seen: they rewrite the scene's buffers in place) and is valid until the next rt_upload_scene* or rt_destroy of
+ * this context, or until the caller's buffers are freed; replaying later is a use after free.  A new camera or new
+ * parameters need a new capture.  RT_FLAG_ACCUMULATE is refused under capture (RT_ERR_ARG): the sample count that divides
+ * the running sums is host state.  Replays on one GPU share the scratch array like any other calls: one at a time.
+ * (tests/test_zz_no_alloc.py captures a primary + shadow frame and a path-traced frame with torch.cuda.graph and replays
+ * each three times, bit-identical to rt_render.) */
 #define RT_STATIC_SCRATCH_BYTES   (32u << 20)
 #define RT_STATIC_MAX_PATH_PIXELS 279552u
 int rt_render_static(rt_ctx *ctx, const rt_render_params *params, void *d_radiance, void *d_prim_ids, void *d_hit_t,
@@ -245,7 +258,9 @@ typedef struct {
     uint64_t node_visits;        /* BVH nodes fetched (RT_FLAG_COUNTERS only) */
     uint64_t tri_tests;          /* ray/triangle tests (RT_FLAG_COUNTERS only) */
     uint64_t mesh_aabb_tests;    /* per-mesh culls evaluated (RT_FLAG_COUNTERS only) */
-    double   kernel_ms;          /* device time of the last rt_render's kernels (TIME_KERNELS) */
+    double   kernel_ms;          /* RT_FLAG_TIME_KERNELS: sum of the begin-to-end spans (HIP event pairs) of the timed frames
+                                    since the last rt_get_counters.  One frame at a time that is device time; with frames in
+                                    flight the spans of different sets OVERLAP, so the sum exceeds wall time by up to n */
     uint32_t kernel_launches;
     uint32_t _pad;
     uint64_t wave_node_iters;    /* wave-level trips of the node loop / of the triangle loop */

@@ -718,6 +718,7 @@ int rt_upload_scene_ex(rt_ctx *c, const rt_triangle *tris, size_t n_tris, const 
     c->bvh_host_stale = false;
     c->has_scene = true;
     c->accum_samples = 0;
+    c->accum_dirty = true;           // the running sums belong to the scene before this one: the next path-traced frame restarts them
     invalidate_coverage(c);
     return RT_OK;
 }
@@ -972,6 +973,7 @@ int rt_set_view(rt_ctx *c, const float m[16], const float pos[3], uint32_t width
         select_set(c, c->cur_set);
         c->n_px = n_px;
         c->accum_samples = 0;
+        c->accum_dirty = true;       // the new accumulation buffer is uninitialised: restart, whatever the camera and coverage are
         c->has_view = had_view;
     }
     if (c->has_view && (std::memcmp(c->V.m, m, 64) != 0 || std::memcmp(c->V.pos, pos, 12) != 0))
@@ -1073,7 +1075,8 @@ static int launch_frame(rt_ctx *c, const rt_render_params &P, const RtShardDev &
             int in = RT_CNT_QUEUE_A, out = RT_CNT_QUEUE_B;
             for (uint32_t seg = 1; seg < P.max_segments; ++seg) {
                 HIPCHK(c, hipMemsetAsync(T.cnt + out, 0, sizeof(unsigned long long), c->stream));
-                const bool split = c->tune.path_split && !(P.flags & (RT_FLAG_BRUTE_FORCE | RT_FLAG_STATIC_GRID));
+                // (an empty tree has nothing to walk: k_path_trace would hand out no path and leave the hit records unwritten -- the fused kernel ends such paths itself)
+                const bool split = c->tune.path_split && c->S.n_nodes != 0u && !(P.flags & (RT_FLAG_BRUTE_FORCE | RT_FLAG_STATIC_GRID));
                 if (split)
                     HIPCHK(c, rtk_launch_path_trace_shade(c->stream, c->S, P.flags, cap, seg + 1 == P.max_segments, T.contrib, (uint32_t)c->n_px,
                                                           in == RT_CNT_QUEUE_A ? T.qa : T.qb, T.hits, in == RT_CNT_QUEUE_A ? T.qb : T.qa,
@@ -1208,6 +1211,21 @@ int rt_render_static(rt_ctx *c, const rt_render_params *params, void *d_radiance
         return fail(c, RT_ERR_ARG, msg);
     }
     HIPCHK(c, hipSetDevice(c->device));
+    // ONE stream for every static call of a context, whatever rt_render did in between: with frames in flight the sets (and
+    // their streams) take turns, and two static calls on two streams would race on the one scratch array.
+    // Set 0's stream it is; the context's "frame rendered last" aliases then name set 0.
+    if (c->n_sets > 1) select_set(c, 0);
+    // Under stream capture (a caller recording this call into a HIP graph; the null stream cannot be captured) every
+    // argument of every launch is frozen into the graph: see include/rt_amd.h for what a replay may rely on.  What is wrong
+    // by construction is refused: the divisor of an accumulating frame's resolve is host state (samples so far).
+    {
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        if (c->stream && hipStreamIsCapturing(c->stream, &cap) != hipSuccess) { (void)hipGetLastError(); cap = hipStreamCaptureStatusNone; }
+        if (cap == hipStreamCaptureStatusActive && path && (P.flags & RT_FLAG_ACCUMULATE))
+            return fail(c, RT_ERR_ARG, "rt_render_static: RT_FLAG_ACCUMULATE cannot be captured into a graph (the sample count that divides the sums is host state)");
+        if (cap == hipStreamCaptureStatusInvalidated)
+            return fail(c, RT_ERR_HIP, "rt_render_static: the stream's capture has been invalidated");
+    }
 
     RenderTargets T{};
     T.rgba = (float *)d_radiance; T.prim = (uint32_t *)d_prim_ids; T.t = (float *)d_hit_t; T.accum = (float *)d_accum;

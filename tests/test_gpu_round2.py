@@ -204,7 +204,7 @@ def test_sixteen_sample_batch_at_1080p_and_config3_four_way_shard_at_4k():
         assert np.array_equal(total, full)
 
 
-@pytest.mark.parametrize("n", [2, 3])
+@pytest.mark.parametrize("n", [2, 3, 4])      # 4: bench.py's default (k_stream8 from n = 3 on)
 def test_frames_in_flight_inside_one_context(n):
     """rt_set_frames_in_flight: rt_render takes n sets of frame buffers / streams in turn without waiting for the frame
     before.  Every frame must still be the serial frame, bit for bit, readers must see the frame rendered last, a scene
@@ -349,7 +349,7 @@ def test_get_stream_and_tile_exchange_with_frames_in_flight():
         assert ctx.get_stream() == own                            # one frame at a time: the context's ordinary stream again
 
 
-@pytest.mark.parametrize("n", [1, 3])
+@pytest.mark.parametrize("n", [1, 3, 4])
 def test_present_async_delivers_the_bytes_of_each_frame_in_flight(n):
     """rt_present_async / rt_present_wait: the Bgra8UnormSrgb bytes of the frame rendered last, encoded and copied on that
     frame's stream while the next frames render.  Every ticket's bytes must be those rt_read_bgra8_srgb gives for the same

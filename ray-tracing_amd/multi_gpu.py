@@ -20,6 +20,70 @@ These helpers only move tensors; they work on any torch device.
 import numpy as np
 
 
+def launch_ranks(n, argv, poll_s=0.2, grace_s=5.0, env_extra=None):
+    """Start n rank processes (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment; rank 0 inherits stdout, the
+    others' stdout is dropped) and wait for them by POLLING: the first rank that exits with a non-zero status ends the run --
+    its siblings, which would otherwise sit in a collective until its timeout, are terminated (they are fresh child
+    processes of a parent that never touches a GPU; nothing is exec'ed over a process that did) -- and that status is
+    returned at once.  0 when every rank exited with 0.  bench.py --gpus N without a launcher runs through this."""
+    import os
+    import socket
+    import subprocess
+    import time
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if env_extra:
+            env.update(env_extra)
+        procs.append(subprocess.Popen(list(argv), env=env, stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    live = set(range(n))
+    while live and rc == 0:
+        for r in sorted(live):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            live.discard(r)
+            if code != 0:
+                rc = abs(code) or 1
+                break
+        if live and rc == 0:
+            time.sleep(poll_s)
+    if rc != 0:
+        for r in live:
+            procs[r].terminate()
+        deadline = time.time() + grace_s
+        for r in live:
+            try:
+                procs[r].wait(timeout=max(0.1, deadline - time.time()))
+            except subprocess.TimeoutExpired:
+                procs[r].kill()
+                procs[r].wait()
+    return rc
+
+
+def frames_identical(a, b):
+    """Bitwise comparison of two frames (numpy arrays of one dtype and shape): what bench.py prints at N > 1 in tiles mode
+    as parity.combined_equals_unsharded -- the frame rank 0 holds after the exchange against the same frame rendered by one
+    rank alone.  Tiles are disjoint and every pixel is computed by exactly one rank with the same arithmetic: bits, not RMSE."""
+    a, b = np.ascontiguousarray(a), np.ascontiguousarray(b)
+    same = a.shape == b.shape and a.dtype == b.dtype and a.tobytes() == b.tobytes()
+    differing = 0 if same else (int((a.reshape(-1).view(np.uint8) != b.reshape(-1).view(np.uint8)).sum()) if a.shape == b.shape and a.dtype == b.dtype else -1)
+    return {"identical": bool(same), "differing_bytes": differing, "pixels": int(a.size // 4) if a.ndim else 0}
+
+
+def frames_rmse(a, b):
+    """RMSE of two radiance frames in float64: the gate of the sample-sliced mode (summation order differs from one GPU doing
+    all samples, so bits are not expected; BASELINE.json: <= 1e-3)."""
+    d = np.asarray(a, np.float64).reshape(-1) - np.asarray(b, np.float64).reshape(-1)
+    return float(np.sqrt(np.mean(d * d))) if d.size else 0.0
+
+
 def tile_owner(width, height, tile, count):
     """(H, W) int array: rank that owns each pixel under round-robin tile sharding
     (tile index = ty * tiles_x + tx; owner = index % count), as rt_render does."""

@@ -47,6 +47,11 @@ def _worker(rank, world, port, out):
     t = torch.from_numpy(mine.copy())
     multi_gpu.combine_tiles(t)
     tiles_ok = t.numpy().tobytes() == full.tobytes()
+    # bench.py's N > 1 self-check (parity.combined_equals_unsharded): the combined frame against the frame of one rank alone
+    chk = multi_gpu.frames_identical(t.numpy(), full)
+    tiles_ok = tiles_ok and chk["identical"] and chk["differing_bytes"] == 0 and chk["pixels"] == W * H
+    broken = t.numpy().copy(); broken[3, 5, 1] = np.nextafter(broken[3, 5, 1], np.float32(9.0))
+    tiles_ok = tiles_ok and not multi_gpu.frames_identical(broken, full)["identical"] and multi_gpu.frames_identical(broken, full)["differing_bytes"] >= 1
     # the same tiles through the packed gather: rank 0 ends with the full frame, bit for bit
     # (host packer: the layout the HIP kernels k_tile_pack / k_tile_unpack are held to in tests/test_gpu_round2.py)
     g2 = multi_gpu.TileGather(W, H, 16, world, rank)
@@ -72,6 +77,7 @@ def _worker(rank, world, port, out):
     ref_acc, _ = orc.render_path(s, v, 2 * world, 4, seed=3, threads=1)
     ref = orc.resolve(ref_acc, 2 * world)
     rmse = float(np.sqrt(np.mean((res.astype(np.float64) - ref.astype(np.float64)) ** 2)))
+    assert abs(multi_gpu.frames_rmse(res, ref) - rmse) < 1e-12      # bench.py's samples-mode self-check uses this helper
     # the same sum as a direct reduce-scatter + gather (point-to-point sends instead of a ring)
     flat = torch.from_numpy(acc.copy()).reshape(-1)
     sr = multi_gpu.SampleReduce(flat.numel(), world, rank)
@@ -123,3 +129,39 @@ def test_bench_self_launch_starts_ranks_and_fails_loudly_without_gpus():
                        env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode != 0
     assert r.stderr.count("needs a GPU") == 2 and "{" not in r.stdout
+
+
+def test_launch_ranks_ends_the_run_at_once_when_one_rank_dies(tmp_path):
+    """bench.py --gpus N without a launcher (multi_gpu.launch_ranks): the ranks are polled, the first one that exits with an
+    error takes its siblings down -- they would sit in a collective until its timeout -- and its status is handed on at once
+    (VERDICT r2 item 5a).  With every rank fine the status is 0 and rank 0's stdout is the parent's."""
+    import subprocess
+    import time
+    sys.path.insert(0, ROOT)
+    import ray_tracing_amd  # noqa: F401
+    from ray_tracing_amd import multi_gpu
+    script = tmp_path / "rank.py"
+    script.write_text(
+        "import os, sys, time\n"
+        "r = int(os.environ['RANK']); assert os.environ['WORLD_SIZE'] == '3' and os.environ['MASTER_ADDR'] == '127.0.0.1'\n"
+        "open(os.path.join(os.environ['OUT_DIR'], f'started{r}'), 'w').write(str(os.getpid()))\n"
+        "if os.environ.get('FAIL_RANK') == str(r):\n"
+        "    time.sleep(0.5); sys.exit(7)\n"
+        "time.sleep(float(os.environ.get('SLEEP', '0')))\n"
+        "print('line from rank', r)\n")
+    t0 = time.time()
+    rc = multi_gpu.launch_ranks(3, [sys.executable, str(script)], env_extra={"OUT_DIR": str(tmp_path), "FAIL_RANK": "1", "SLEEP": "120"})
+    assert rc == 7 and time.time() - t0 < 30
+    for r in (0, 2):                                    # the siblings are gone, not waiting out their two minutes
+        pid = int((tmp_path / f"started{r}").read_text())
+        for _ in range(50):
+            if not os.path.exists(f"/proc/{pid}") or open(f"/proc/{pid}/stat").read().split()[2] == "Z":
+                break
+            time.sleep(0.1)
+        else:
+            pytest.fail(f"rank {r} (pid {pid}) still runs")
+    r = subprocess.run([sys.executable, "-c",
+                        "import sys; sys.path.insert(0, %r); import ray_tracing_amd; from ray_tracing_amd import multi_gpu; "
+                        "sys.exit(multi_gpu.launch_ranks(3, [sys.executable, %r], env_extra={'OUT_DIR': %r}))" % (ROOT, str(script), str(tmp_path))],
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and r.stdout.strip() == "line from rank 0"

@@ -509,6 +509,70 @@ bool rt_bvh_refit(RtBvhBuildResult *bvh, const rt_triangle *tris, const rt_verte
     return true;
 }
 
+// Experiment (RT_TUNE_WIDE_ORDER, round 3): the wide nodes' ORDER IN MEMORY, a pure re-indexing -- the
+// tree, its boxes, every ray's sequence of visits and the results stay what they are.  The walk in rt_bvh_widen already lays
+// the children of a node out side by side and continues with the subtree of the last child (mode 0).
+//   1: breadth-first over the whole tree (children still side by side; a level is one contiguous block)
+//   2: breadth-first for the top of the tree (until a level holds >= 4096 nodes), the subtrees below it one after the other
+//      in mode 0's order -- the "hot block + treelets" layout
+//   3: a random permutation (root first): what is locality worth at all?
+//   4: mode 0 with padding nodes, so that a group of 2 or 4 siblings never straddles one more 128-B line than it has to
+static void wide_reorder(RtWideTree *w, int mode) {
+    const size_t n = w->nodes.size();
+    if (n < 2 || mode <= 0 || mode > 4) return;
+    std::vector<uint32_t> order;            // order[new index] = old index; 0xFFFFFFFF = a padding node
+    order.reserve(n + n / 4);
+    auto children = [&](uint32_t i, uint32_t *c) {
+        int m = 0;
+        for (int k = 0; k < 4; ++k) if (w->nodes[i].child[k] >= 0) c[m++] = (uint32_t)w->nodes[i].child[k];
+        return m;
+    };
+    auto cluster_dfs = [&](uint32_t root_old, bool emit_root) {     // mode 0's order below root_old
+        std::vector<uint32_t> st;
+        if (emit_root) order.push_back(root_old);
+        st.push_back(root_old);
+        while (!st.empty()) {
+            uint32_t i = st.back(); st.pop_back();
+            uint32_t c[4]; int m = children(i, c);
+            if (mode == 4 && (m == 2 || m == 4) && (order.size() & 1u)) order.push_back(0xFFFFFFFFu);
+            for (int k = 0; k < m; ++k) { order.push_back(c[k]); st.push_back(c[k]); }
+        }
+    };
+    if (mode == 1 || mode == 2) {
+        std::vector<uint32_t> level{0u}, next;
+        order.push_back(0u);
+        while (!level.empty()) {
+            next.clear();
+            for (uint32_t i : level) { uint32_t c[4]; int m = children(i, c); for (int k = 0; k < m; ++k) { order.push_back(c[k]); next.push_back(c[k]); } }
+            if (mode == 2 && next.size() >= 4096) { for (uint32_t i : next) cluster_dfs(i, false); break; }
+            level.swap(next);
+        }
+    } else if (mode == 3) {
+        for (uint32_t i = 0; i < n; ++i) order.push_back(i);
+        uint64_t x = 0x9E3779B97F4A7C15ull;
+        for (size_t i = n - 1; i > 1; --i) {
+            x ^= x << 13; x ^= x >> 7; x ^= x << 17;
+            std::swap(order[i], order[1 + (size_t)(x % i)]);
+        }
+    } else cluster_dfs(0u, true);
+    std::vector<uint32_t> newidx(n, 0xFFFFFFFFu);
+    for (size_t i = 0; i < order.size(); ++i) if (order[i] != 0xFFFFFFFFu) newidx[order[i]] = (uint32_t)i;
+    std::vector<RtWideNode> nodes(order.size());
+    std::vector<RtWideSrc> src(order.size());
+    for (size_t i = 0; i < order.size(); ++i) {
+        RtWideNode W; RtWideSrc S;
+        if (order[i] == 0xFFFFFFFFu) {           // padding: an empty node nobody points at
+            std::memset(&W, 0, sizeof W);
+            for (int k = 0; k < 4; ++k) { W.child[k] = RT_CHILD_NONE; S.slot[k] = RT_WIDE_EMPTY; }
+        } else {
+            W = w->nodes[order[i]]; S = w->src[order[i]];
+            for (int k = 0; k < 4; ++k) if (W.child[k] >= 0) W.child[k] = (int32_t)newidx[W.child[k]];
+        }
+        nodes[i] = W; src[i] = S;
+    }
+    w->nodes.swap(nodes); w->src.swap(src);
+}
+
 void rt_bvh_widen(const RtBvhBuildResult &bvh, RtWideTree *out) {
     auto t0 = std::chrono::steady_clock::now();
     out->nodes.clear(); out->src.clear(); out->max_depth = 0; out->stack_need = 0;
@@ -561,6 +625,7 @@ void rt_bvh_widen(const RtBvhBuildResult &bvh, RtWideTree *out) {
         }
         out->nodes[it.wide] = W; out->src[it.wide] = S;
     }
+    if (const char *e = std::getenv("RT_TUNE_WIDE_ORDER")) wide_reorder(out, std::atoi(e));   // experiments: the nodes' order in memory
     rt_wide_requantise(bvh, out);       // the boxes, on all threads (the walk above only fixes topology and order)
     // worst-case stack use: with n children hit, n-1 wait on the stack while the first subtree is walked, n-2
     // during the second, ...; the worst order visits the neediest subtree first

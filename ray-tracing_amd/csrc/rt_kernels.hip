@@ -245,6 +245,14 @@ __device__ __forceinline__ void wide_decide(Q q0, Q q1, Q q2, Q q3, f3 o, f3 inv
         if (dmy == 12345.678f) ref[0] = RT_CHILD_NONE;
     }
 #endif
+#ifdef RT_EXP_EXTRA_VALU_SHADOW   // experiment only: N more VALU instructions in the steps of +Y shadow rays alone (what would a cheaper shadow step buy?)
+    if (inv.x == RT_WIDE_INV_MAX && inv.z == RT_WIDE_INV_MAX) {
+        float dmy = Ax;
+#pragma unroll
+        for (int i = 0; i < RT_EXP_EXTRA_VALU_SHADOW; ++i) dmy = __builtin_fmaf(dmy, Ay, Az);
+        if (dmy == 12345.678f) ref[0] = RT_CHILD_NONE;
+    }
+#endif
     if (ref[0] != RT_CHILD_NONE) cur = ref[0];
     else cur = stack_pop(sp, stk, ovf);
 }

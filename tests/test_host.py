@@ -453,3 +453,34 @@ def test_rust_sys_source_binds_every_entry_point_of_the_header():
     bound = set(re.findall(r"pub fn (rt_[a-z0-9_]+)", rust))
     assert declared == bound, (sorted(declared - bound), sorted(bound - declared))
     assert declared == set(rt.RT_SYMBOLS)
+
+
+def test_rust_node_shim_source_is_complete_against_the_sys_crate_and_itself():
+    """integration/node_shim.rs is unbuilt source too (it called three functions that nowhere existed).  What can be
+    held without a compiler: every rt_* function, type and constant it names is declared by the -sys crate; every free
+    function it calls is defined in the file; it uses the round-2 API the header recommends for a node that keeps submitting
+    (dirty-range updates, frames in flight, asynchronous presentation) and not the blocking read."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    shim = open(os.path.join(root, "integration", "node_shim.rs")).read()
+    code = re.sub(r'r#".*?"#', '""', shim, flags=re.S)                                  # the WGSL text is not Rust
+    code = "\n".join(line.split("//")[0] for line in code.splitlines() if not line.lstrip().startswith("//"))
+    names_in_strings = set(re.findall(r"\b(rt_[a-z0-9_]+)\b", " ".join(re.findall(r'"((?:[^"\\]|\\.)*)"', code))))
+    code = re.sub(r'"(?:[^"\\]|\\.)*"', '""', code)                                   # messages and labels neither
+    rust = open(os.path.join(root, "integration", "rt-amd-sys", "src", "lib.rs")).read()
+    sys_names = set(re.findall(r"pub fn (rt_[a-z0-9_]+)", rust)) | set(re.findall(r"pub struct (rt_[a-z0-9_]+)", rust)) | \
+        set(re.findall(r"pub const (RT_[A-Z0-9_]+)", rust))
+    used = set(re.findall(r"\b(rt_[a-z0-9_]+)\b", code)) - {"rt_amd_sys"}
+    assert names_in_strings                                                               # (error messages name the calls they report)
+    used |= set(re.findall(r"\b(RT_[A-Z0-9_]+)\b", code))
+    assert used <= sys_names, sorted(used - sys_names)
+    defined = set(re.findall(r"\bfn ([a-z_0-9]+)\s*[<(]", code))
+    called = set(re.findall(r"(?<![.:\w])([a-z_][a-z_0-9]*)\s*\(", code)) - sys_names
+    rust_builtins = {"map", "matches", "panic", "assert_eq", "vec", "single", "filter", "if", "match", "for", "fn", "unsafe", "return", "texture_2d",
+                     "fullscreen_shader_vertex_state", "derive", "load", "let"}
+    missing = {c for c in called - defined - rust_builtins if not c[0].isupper()}
+    assert not missing, sorted(missing)
+    for name in ("to_repr_c", "signatures", "write_to_target"):          # the three that did not exist
+        assert name in defined
+    for api in ("rt_update_vertex_range", "rt_set_frames_in_flight", "rt_present_async", "rt_present_wait"):
+        assert api in used
+    assert "rt_read_bgra8_srgb" not in used

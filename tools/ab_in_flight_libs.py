@@ -6,8 +6,13 @@ if len(sys.argv) > 1:
     for rep in range(2):
         for lib in sys.argv[1].split(","):
             env = dict(os.environ)
+            name = lib
+            lib, _, envs = lib.partition("@")                 # "default@RT_TUNE_X=1@RT_TUNE_Y=2": the build plus environment for that run
+            for kv in filter(None, envs.split("@")):
+                k, _, v = kv.partition("=")
+                env[k] = v
             if lib != "default": env["RT_AMD_LIB"] = os.path.join(root, lib)
-            env["AB_NAME"] = lib
+            env["AB_NAME"] = name
             subprocess.run([sys.executable, "-u", os.path.abspath(__file__)], env=env, check=True, timeout=300)
     sys.exit(0)
 sys.path[:0] = [root]
@@ -33,7 +38,7 @@ for kind in os.environ.get("AB_KINDS", "field,soup").split(","):
             best = min(best, (time.perf_counter() - t0) / 60 * 1e3)
         res.append(best)
     import zlib
-    print("%-6s %-34s 1 in flight %.4f ms   4 in flight %.4f ms   nodes/ray %.2f tris/ray %.2f  prim crc %08x" % (
+    print("%-6s %-34s 1 in flight %.4f ms   4 in flight %.4f ms   nodes/ray %.2f tris/ray %.2f  prim crc %08x rgba crc %08x" % (
         kind, os.environ.get("AB_NAME", "default"), res[0], res[1], c.node_visits / (c.rays_primary + c.rays_shadow),
-        c.tri_tests / (c.rays_primary + c.rays_shadow), zlib.crc32(ctx.read_prim_ids().tobytes())), flush=True)
+        c.tri_tests / (c.rays_primary + c.rays_shadow), zlib.crc32(ctx.read_prim_ids().tobytes()), zlib.crc32(ctx.read_radiance().tobytes())), flush=True)
     ctx.close()

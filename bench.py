@@ -157,6 +157,39 @@ def alg_bytes_of(cnt, info, spp):
             cnt.rays_primary * 24 + hits * 80)
 
 
+def lane_gathers_of(cnt):
+    """64-B gather equivalents of one instrumented launch: a node visit is 4 x dwordx4 per lane (64 B), a record test 3 (48 B),
+    a per-mesh cull 2 (32 B).  The unit rt_measure_gather_rates' ceilings are in."""
+    return cnt.node_visits + 0.75 * cnt.tri_tests + 0.5 * cnt.mesh_aabb_tests
+
+
+def gather_block(rates, lane_gathers, ms_timed, ms_alone=None, beyond_l2_bytes=None):
+    """The roofline in the kernel's own currency: lane-level 64-B gathers per second against what this
+    GPU's memory system delivers to exactly that access pattern, measured in this run (rt_measure_gather_rates)."""
+    if not rates or ms_timed <= 0:
+        return None
+    ach = lane_gathers / (ms_timed * 1e-3) / 1e9
+    top = rates["l2_2MiB"]["independent"]
+    out = {"lane_gathers_per_frame": int(lane_gathers),
+           "lane_gathers_are": "64-B gather equivalents: node visits (4 x dwordx4 per lane) + 3/4 x record tests + 1/2 x mesh culls, counted",
+           "achieved_Ggather_s": round(ach, 1), "ceiling_Ggather_s": round(top, 1),
+           "ceiling_is": "independent random 64-B gathers from a buffer that every XCD's L2 holds, 8 waves per SIMD, every lane of a wave a DIFFERENT line: what the CUs' vector-memory "
+                         "front end passes to fully divergent waves when every gather hits a cache.  Lanes of a wave that fetch the same node cost it one line, so partly coherent waves "
+                         "(primary rays near the top of the tree) can exceed it: frac is an upper bound on the front end's load, TA_BUSY (in_flight.utilisation.vmem_front_end) the hardware's own figure",
+           "frac": round(ach / top, 4),
+           "ceilings_by_level_Ggather_s": {k: round(v["independent"], 1) for k, v in rates.items()},
+           "dependent_chain_Ggather_s": {k: round(v["dependent"], 1) for k, v in rates.items()},
+           "measured_in_this_run": True}
+    if ms_alone:
+        out["achieved_one_frame_at_a_time_Ggather_s"] = round(lane_gathers / (ms_alone * 1e-3) / 1e9, 1)
+    if beyond_l2_bytes:
+        b = beyond_l2_bytes / 64.0 / (ms_timed * 1e-3) / 1e9
+        out["beyond_l2"] = {"Ggather_s": round(b, 1), "ceiling_Ggather_s": round(rates["hbm_1GiB"]["independent"], 1),
+                            "frac": round(b / rates["hbm_1GiB"]["independent"], 4),
+                            "is": "HBM + Infinity Cache bytes per frame (FETCH_SIZE + WRITE_SIZE of the committed passes) / 64 B over the frame time, against random 64-B gathers from 1 GiB"}
+    return out
+
+
 def load_pmc(rt):
     """profiles/pmc_traffic.json, and whether the library that runs is the one its passes were collected on."""
     tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
@@ -173,7 +206,7 @@ def load_pmc(rt):
         return None, False, False, f"no usable profiles/pmc_traffic.json: {str(ex)[:80]}"
 
 
-def side_workload(rt, orc, name, local_rank, steps, in_flight, pmc_section=None, check=True):
+def side_workload(rt, orc, name, local_rank, steps, in_flight, pmc_section=None, check=True, rates=None):
     """A driver-timed figure for another BASELINE config, measured after the timed region on a context of its own; never
     `value`.  Frames in flight as asked (path-traced frames overlap two at a time whatever n > 1 says) and one at a time; the
     one-at-a-time launch time gives SURVEY 8d's algorithmic-bytes fraction; path workloads are compared with the oracle's walk
@@ -215,8 +248,21 @@ def side_workload(rt, orc, name, local_rank, steps, in_flight, pmc_section=None,
                "frac": round(alg / (ms_1 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                "frac_is": "SURVEY 8d's algorithmic bytes per frame / frame time one at a time / 8 TB/s (the caches serve most of those bytes)",
                "frac_at_timed_rate": round(alg / (ms_n * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+        g = gather_block(rates, lane_gathers_of(cnt), ms_n, ms_1)
+        if g:
+            for k in ("ceilings_by_level_Ggather_s", "dependent_chain_Ggather_s", "lane_gathers_are", "ceiling_is"):
+                g.pop(k, None)
+            out["gather"] = g
         if pmc_section is not None:
             out["counters"] = pmc_section
+            kb = pmc_section.get("k_path_bounce<false>") if isinstance(pmc_section, dict) else None
+            if kb and rates and kb.get("avg_duration_us_under_pmc"):
+                r = kb["hbm_bytes_per_launch"] / 64.0 / (kb["avg_duration_us_under_pmc"] * 1e-6) / 1e9
+                out["bounce_launch_beyond_l2"] = {"Ggather_s": round(r, 1), "TBps": round(r * 64 / 1e3, 2),
+                                                  "ceiling_Ggather_s": round(rates["hbm_1GiB"]["independent"], 1),
+                                                  "frac": round(r / rates["hbm_1GiB"]["independent"], 4),
+                                                  "is": "k_path_bounce alone: HBM + Infinity Cache bytes per launch / 64 B / launch duration, against random 64-B gathers from 1 GiB (from 4 GiB: "
+                                                        f"{round(rates['hbm_4GiB']['independent'], 1)})"}
         if check and spp:
             tree = orc.Tree(*ctx.read_bvh(), ctx.read_bvh_wide() if info.n_wide_nodes else None)
             osc = orc.Scene(scene.triangles, scene.meshes, scene.vertices, scene.materials)
@@ -503,6 +549,13 @@ def main():
         ctx.set_view(views[0][0], views[0][1], W, H)
         del acc_r, red_r
 
+    rates = None
+    if rank == 0 and world == 1:
+        try:
+            ctx.synchronize()
+            rates = rt.measure_gather_rates(local_rank)      # ~1 s, 4 GiB of scratch; in this process (no child, no exec)
+        except Exception:
+            rates = None
     if rank == 0:
         import oracle_py as orc
         ms_per_step = dt / args.steps * 1e3
@@ -525,8 +578,7 @@ def main():
         # which kernel the flags select (rtk_launch_primary)
         wide = bool(info.n_wide_nodes) and not (flags & rt.FLAG_BINARY_TREE)
         forced = os.environ.get("RT_TUNE_STREAM_WAVES", "")
-        pooled = os.environ.get("RT_TUNE_POOL_DEP", "0") not in ("", "0")
-        k7 = f"k_stream<false, {'true' if wide else 'false'}, {'true' if pooled else 'false'}>"
+        k7 = f"k_stream<false, {'true' if wide else 'false'}>"
         k8 = f"k_stream8<false, {'true' if wide else 'false'}>"
         if spp:
             kernel = kernel_timed = "k_path_start+k_path_bounce (whole frame)"
@@ -535,8 +587,8 @@ def main():
         elif flags & rt.FLAG_WAVE_TRAVERSAL:
             kernel = kernel_timed = "k_primary<false, true>"
         else:
-            kernel = k8 if forced == "8" and not pooled else k7                                   # one frame at a time
-            kernel_timed = k8 if (forced == "8" or (forced == "" and n_in_flight >= 3)) and not pooled else k7   # the timed region
+            kernel = k8 if forced == "8" else k7                                   # one frame at a time
+            kernel_timed = k8 if forced == "8" or (forced in ("", "0") and n_in_flight >= 3) else k7   # the timed region
         # Counters of the committed PMC passes (profiles/pmc_traffic.json; rocprofv3 --pmc cannot run inside this process):
         # quoted only for the workload AND the very kernel binary they were collected on -- the file records the kernel's
         # symbol, registers, spills and the hash of the device code object (tools/kernel_resources.py); a library built
@@ -577,7 +629,15 @@ def main():
                     busy = tf["valu_insts_per_launch"] / N_SIMDS / (ms_per_step * 1e-3) / peak_rate
                     hbm_if = tf["hbm_bytes_per_launch"] / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS
                     util = {"valu": round(busy, 4), "hbm": round(hbm_if, 4)}
-                    top = max(util, key=util.get)
+                    lg_ = sum(lane_gathers_of(c_) for c_ in cnts) / n_views
+                    # the vector-memory front end by the hardware's own counter: TA_BUSY of the serialised pass, carried over to
+                    # the timed frame time (the same fetches in less time)
+                    if tf.get("ta_busy") and tf.get("avg_duration_us_under_pmc"):
+                        util["vmem_front_end"] = round(tf["ta_busy"] * tf["avg_duration_us_under_pmc"] * 1e-3 / ms_per_step, 4)
+                    if rates:
+                        util["gathers_vs_divergent_ceiling"] = round(lg_ / (ms_per_step * 1e-3) / 1e9 / rates["l2_2MiB"]["independent"], 4)
+                        util["beyond_l2_gathers"] = round(tf["hbm_bytes_per_launch"] / 64.0 / (ms_per_step * 1e-3) / 1e9 / rates["hbm_1GiB"]["independent"], 4)
+                    top = max((k_ for k_ in util if k_ != "gathers_vs_divergent_ceiling"), key=util.get)
                     in_flight_block = {
                         "kernel": kernel_timed, "frames_in_flight": n_in_flight, "ms_per_frame": round(ms_per_step, 4),
                         "valu": {"busy": round(busy, 4), "lanes_active": tf["valu_lanes_active"], "frac": round(busy * tf["valu_lanes_active"], 4),
@@ -585,8 +645,13 @@ def main():
                                  "busy_is": "VALU wave-instructions per launch / (1,024 SIMDs x calibrated issue rate x ms_per_step)"},
                         "hbm_frac": round(hbm_if, 4), "traffic": tf["hbm_bytes_per_launch"], "l2_hit_rate": tf.get("l2_hit_rate"),
                         "ta_busy_alone": tf.get("ta_busy"),
+                        "utilisation": util,
+                        "utilisation_is": "valu: issue rate against the calibrated peak; vmem_front_end: TA_BUSY of the serialised counter pass x its launch duration / ms_per_step; "
+                                          "gathers_vs_divergent_ceiling: counted lane-level 64-B gathers per second against rt_measure_gather_rates' cache-resident ceiling, which "
+                                          "is for waves whose 64 lanes all fetch different lines -- lanes that share a node cost the front end one line (profiles/r3/gather_front_end_variants.txt), "
+                                          "so this OVERSTATES its load; beyond_l2_gathers: HBM + Infinity Cache bytes / 64 B against random gathers from 1 GiB; hbm: the same bytes against the 8 TB/s streaming peak",
                         "bound": (top if util[top] >= 0.65 else "latency"),
-                        "bound_rule": "the pipe with the highest utilisation names the bound if that is >= 0.65, else latency of dependent gathers",
+                        "bound_rule": "the highest of valu / vmem_front_end / beyond_l2_gathers / hbm names the bound if it is >= 0.65, else latency of dependent gathers",
                         "counters_from": tf.get("collected_with")}
         # The bound: SURVEY 8d names HBM as the nominal roofline and `achieved`/`frac` keep that definition (ALGORITHMIC
         # bytes -- every lane's node / record fetch, most of them served by L1 / L2 / Infinity Cache -- over kernel time),
@@ -599,6 +664,11 @@ def main():
             bound_alone = "hbm (nominal; no current counters)"
         bound = in_flight_block["bound"] if in_flight_block else bound_alone
         frac_timed = alg_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS
+        g_main = None
+        if not spp:
+            tf_ = (tj or {}).get("in_flight") if (tj is not None and pmc.get("quoted")) else None
+            g_main = gather_block(rates, sum(lane_gathers_of(c_) for c_ in cnts) / n_views, ms_per_step, kernel_ms if overlapped else None,
+                                  tf_["hbm_bytes_per_launch"] if (overlapped and tf_ and tf_.get("kernel") == kernel_timed) else traffic)
         out = {
             "metric": "Mrays/s", "value": round(value, 2), "unit": "Mrays/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
@@ -626,6 +696,7 @@ def main():
                              "kernel_ms_in_flight": round(kernel_ms_in_flight, 4),
                              "kernel_ms_in_flight_is": f"the same events in the timed region, {n_in_flight} frames in flight: begin-to-end time of launches that share the GPU",
                              "kernel_in_flight": kernel_timed} if overlapped else {}),
+                         **({"gather": g_main} if g_main else {}),
                          "algorithmic_bytes_per_launch": int(alg_one),
                          "node_visits": int(sum(c.node_visits for c in cnts) / n_views), "tri_tests": int(sum(c.tri_tests for c in cnts) / n_views),
                          "bytes_per_ray": round(alg_bytes / max(rays_step, 1), 1)},
@@ -713,7 +784,7 @@ def main():
             # the same fingerprint guard.
             steps_x = max(10, min(args.steps, 50))
             try:
-                ns = side_workload(rt, orc, "soup_1m_1080p_primary_shadow", local_rank, args.steps, n_in_flight, check=False)
+                ns = side_workload(rt, orc, "soup_1m_1080p_primary_shadow", local_rank, args.steps, n_in_flight, check=False, rates=rates)
                 ns["target"] = ">= 1000 Mrays/s primary+shadow at 1080p on a 1M-triangle scene (BASELINE.json north_star)"
                 out["north_star_scene"] = ns
             except Exception as ex:                                              # never fail the bench line for it
@@ -724,7 +795,7 @@ def main():
                     quoted = None
                     if tj is not None and sec in tj:
                         quoted = dict(tj[sec], quoted=True) if fresh_path else {"quoted": False, "stale": True, "why": "the path kernels' device code differs from the one the passes were collected on"}
-                    extra[key] = side_workload(rt, orc, name, local_rank, steps_x, n_in_flight, pmc_section=quoted, check=not args.no_cpu_baseline)
+                    extra[key] = side_workload(rt, orc, name, local_rank, steps_x, n_in_flight, pmc_section=quoted, check=not args.no_cpu_baseline, rates=rates)
                 except Exception as ex:
                     extra[key] = {"error": str(ex)[:120]}
             out["extra"] = extra

@@ -71,7 +71,7 @@ int rt_set_stream(rt_ctx *ctx, void *hip_stream);
  * additions to the running sums (and a restart's clear) wait for that frame's end, so sums and RT_FLAG_ACCUMULATE
  * chains are those of frames rendered one after the other; rt_read_accumulation and rt_resolve_accumulation wait for
  * them.  On a caller's stream (rt_set_stream) all sets run on that one stream and frames serialise.  Costs 24 B per
- * pixel per extra set, and a second set of path queues (120 B per path of a batch) once path-traced frames overlap.
+ * pixel per extra set, and a second set of path queues (104 B per path of a batch) once path-traced frames overlap.
  * With n > 1 every set renders on a stream that has a hardware queue of its own (created with a CU mask of all
  * compute units: ordinary streams share a few queues as the runtime sees fit, and two sets on one queue run their
  * frames strictly one after the other); such streams are of HIP's default kind, so unlike the context's ordinary
@@ -180,8 +180,8 @@ int rt_synchronize(rt_ctx *ctx);
  *     samples it holds is kept in the context.
  *   - keeps the frame's scratch (work-queue heads, counters, path queues, contribution plane) in a static device
  *     array of RT_STATIC_SCRATCH_BYTES = 32 MiB that every GPU the library runs on holds until the process ends.
- *     Primary / shadow frames use 1.2 KB of it at any frame size; path tracing uses 120 B per pixel (one sample per
- *     launch), so frames beyond RT_STATIC_MAX_PATH_PIXELS (279,552; 640x360 fits) return RT_ERR_ARG with a message
+ *     Primary / shadow frames use 1.2 KB of it at any frame size; path tracing uses 104 B per pixel (one sample per
+ *     launch), so frames beyond RT_STATIC_MAX_PATH_PIXELS (322,560; 640x360 fits) return RT_ERR_ARG with a message
  *     that says so.  RT_FLAG_TIME_KERNELS is refused (it creates events).
  *   - calls no hipMalloc / hipFree / hipEventCreate or any other allocating routine, first call included (scene and
  *     view are set up beforehand with rt_upload_scene / rt_set_view, which do allocate).
@@ -202,7 +202,7 @@ int rt_synchronize(rt_ctx *ctx);
  * (tests/test_zz_no_alloc.py captures a primary + shadow frame and a path-traced frame with torch.cuda.graph and replays
  * each three times, bit-identical to rt_render.) */
 #define RT_STATIC_SCRATCH_BYTES   (32u << 20)
-#define RT_STATIC_MAX_PATH_PIXELS 279552u
+#define RT_STATIC_MAX_PATH_PIXELS 322560u
 int rt_render_static(rt_ctx *ctx, const rt_render_params *params, void *d_radiance, void *d_prim_ids, void *d_hit_t,
                      void *d_accum, size_t n_pixels);
 
@@ -299,6 +299,16 @@ int rt_host_bvh_copy(const rt_host_bvh *bvh, void *nodes, size_t node_bytes_tota
 int rt_host_bvh_wide(const rt_host_bvh *bvh, void *wide_nodes, void *wide_src, size_t capacity_nodes,
                      size_t *n_wide, uint32_t *stack_need);
 void rt_host_bvh_free(rt_host_bvh *bvh);
+
+/* ---- measurement aid (no counterpart in the reference; not on the render path) -------------------------------------------
+ * What THIS GPU's memory system delivers to the access pattern of a BVH walk -- every lane one 64-B record (4 x dwordx4) at
+ * its own pseudo-random address -- per level of the hierarchy and at the traversal kernels' occupancy: the denominators
+ * bench.py's roofline.gather uses instead of the HBM streaming peak.  Fills ggather_per_s[0..9] with 10^9 gathers of 64 B per
+ * second, as pairs {independent (throughput), dependent (pointer chase)} for buffers of 16 KiB (vector L1), 2 MiB (L2 of every
+ * XCD), 128 MiB (Infinity Cache), 1 GiB and 4 GiB (HBM).  Allocates 4 GiB of device memory for the call (RT_ERR_OOM if it
+ * cannot) and takes about a second; runs in the caller's process on a stream of its own. */
+#define RT_GATHER_RATE_VALUES 10
+int rt_measure_gather_rates(int device_ordinal, double *ggather_per_s, size_t n_values);
 
 const char *rt_last_error(rt_ctx *ctx);   /* ctx may be NULL: last error of rt_create */
 const char *rt_status_string(int status);

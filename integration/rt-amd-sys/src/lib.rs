@@ -110,7 +110,7 @@ extern "C" {
     pub fn rt_render(ctx: *mut rt_ctx, params: *const rt_render_params) -> c_int;
     pub fn rt_synchronize(ctx: *mut rt_ctx) -> c_int;
     /// The same frame into the caller's device buffers, allocating nothing (scratch in a static 32 MiB device array;
-    /// path tracing up to 279,552 pixels; calls that overlap on one GPU race).
+    /// path tracing up to 322,560 pixels; calls that overlap on one GPU race).
     pub fn rt_render_static(ctx: *mut rt_ctx, params: *const rt_render_params, d_radiance: *mut c_void, d_prim_ids: *mut c_void,
         d_hit_t: *mut c_void, d_accum: *mut c_void, n_pixels: usize) -> c_int;
     pub fn rt_read_radiance(ctx: *mut rt_ctx, rgba: *mut f32, n_floats: usize) -> c_int;
@@ -132,6 +132,8 @@ extern "C" {
     pub fn rt_pack_tiles(ctx: *mut rt_ctx, shard_rank: u32, shard_count: u32, tile_size: u32, d_packed: *mut c_void, bytes: usize) -> c_int;
     pub fn rt_unpack_tiles(ctx: *mut rt_ctx, first_rank: u32, n_ranks: u32, shard_count: u32, tile_size: u32,
         d_packed: *const c_void, slot_bytes: usize) -> c_int;
+    /// Measurement aid: 64-B gather rates of this GPU per level of the memory hierarchy (include/rt_amd.h); 10 values.
+    pub fn rt_measure_gather_rates(device_ordinal: c_int, ggather_per_s: *mut f64, n_values: usize) -> c_int;
     pub fn rt_last_error(ctx: *mut rt_ctx) -> *const c_char;
     pub fn rt_status_string(status: c_int) -> *const c_char;
     pub fn rt_version() -> *const c_char;

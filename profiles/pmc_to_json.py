@@ -3,7 +3,7 @@
 
 usage: python profiles/pmc_to_json.py <workload> <views> <note> main=<pmc dir> [in_flight=<pmc dir>] [path_10m=<pmc dir>] [configs2=<pmc dir>]
 
-  main      passes of the default command with --in-flight 1: k_stream<false, true, false>, every launch alone (what
+  main      passes of the default command with --in-flight 1: k_stream<false, true>, every launch alone (what
             roofline.traffic / valu / hbm_frac quote, over the one-frame-at-a-time launch duration)
   in_flight passes of the same command with RT_TUNE_STREAM_WAVES=8 --in-flight 1: k_stream8<false, true>, the kernel the TIMED
             region launches with >= 3 frames in flight (a counter pass serialises launches, so the kernel is forced and runs
@@ -78,8 +78,8 @@ def derived(c, dur):
 def main():
     workload, views, note = sys.argv[1], int(sys.argv[2]), sys.argv[3]
     dirs = dict(a.split("=", 1) for a in sys.argv[4:])
-    c, dur = collect(dirs["main"], "k_stream<false, true, false>")
-    out = {"workload": workload, "kernel": "k_stream<false, true, false>", "views": views, "pmc_source": note,
+    c, dur = collect(dirs["main"], "k_stream<false, true>")
+    out = {"workload": workload, "kernel": "k_stream<false, true>", "views": views, "pmc_source": note,
            "fetch_correction": 1.0,
            "correction_basis": "profiles/calib/gather_calib.hip (round 1, same pool): 64-B node / 48-B record gathers read FETCH_SIZE = bytes (factor 1.0); a 16-B/lane coalesced stream would need the guide's factor 2",
            "valu_peak_wave_insts_per_s_per_simd": VALU_PEAK}

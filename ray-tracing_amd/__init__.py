@@ -81,7 +81,7 @@ RT_SYMBOLS = ["rt_create", "rt_destroy", "rt_set_stream", "rt_set_frames_in_flig
               "rt_synchronize", "rt_read_radiance", "rt_read_prim_ids", "rt_read_hit_t", "rt_read_bgra8_srgb",
               "rt_read_accumulation", "rt_device_buffers", "rt_resolve_accumulation", "rt_get_counters",
               "rt_encode_bgra8_srgb", "rt_present_async", "rt_present_wait", "rt_tile_slot_bytes", "rt_pack_tiles", "rt_unpack_tiles", "rt_render_static",
-              "rt_get_bvh_info", "rt_read_bvh", "rt_read_bvh_wide", "rt_host_bvh_build", "rt_host_bvh_copy", "rt_host_bvh_wide", "rt_host_bvh_free", "rt_last_error", "rt_status_string", "rt_version"]
+              "rt_get_bvh_info", "rt_read_bvh", "rt_read_bvh_wide", "rt_host_bvh_build", "rt_host_bvh_copy", "rt_host_bvh_wide", "rt_host_bvh_free", "rt_measure_gather_rates", "rt_last_error", "rt_status_string", "rt_version"]
 RTH_SYMBOLS = ["rth_app_create", "rth_app_destroy", "rth_app_finish", "rth_app_update", "rth_app_ctx",
                "rth_last_error", "rth_add_mesh", "rth_add_cuboid", "rth_add_plane", "rth_add_icosphere",
                "rth_add_material", "rth_spawn", "rth_set_transform", "rth_set_aabb", "rth_clear_world",
@@ -139,6 +139,7 @@ def lib():
         "rt_read_bvh_wide": (i, [vp, vp, sz]),
         "rt_host_bvh_wide": (i, [vp, vp, vp, sz, C.POINTER(sz), C.POINTER(C.c_uint32)]),
         "rt_last_error": (C.c_char_p, [vp]), "rt_status_string": (C.c_char_p, [i]), "rt_version": (C.c_char_p, []),
+        "rt_measure_gather_rates": (i, [i, C.POINTER(C.c_double), sz]),
         "rth_app_create": (vp, []), "rth_app_destroy": (None, [vp]), "rth_app_finish": (i, [vp, i]),
         "rth_app_update": (i, [vp, C.POINTER(RenderParams)]), "rth_app_ctx": (vp, [vp]),
         "rth_last_error": (C.c_char_p, [vp]),
@@ -244,6 +245,18 @@ def analytic_sphere_field(n, seed):
         mats["color"][ground.materials.size + k] = (uniform(0.1, 1.0), uniform(0.1, 1.0), uniform(0.1, 1.0), 1.0)
     idx = np.arange(ground.materials.size, ground.materials.size + n, dtype=np.uint32)
     return Scene(ground.triangles, ground.meshes, ground.vertices, mats, spheres, idx)
+
+
+GATHER_LEVELS = ("l1_16KiB", "l2_2MiB", "infinity_cache_128MiB", "hbm_1GiB", "hbm_4GiB")
+
+
+def measure_gather_rates(device=0):
+    """rt_measure_gather_rates: {level: {"independent": Ggather/s, "dependent": Ggather/s}} of 64-B gathers on this GPU."""
+    vals = (C.c_double * 10)()
+    rc = lib().rt_measure_gather_rates(device, vals, 10)
+    if rc != RT_OK:
+        raise RtError(rc, "rt_measure_gather_rates")
+    return {name: {"independent": vals[2 * k], "dependent": vals[2 * k + 1]} for k, name in enumerate(GATHER_LEVELS)}
 
 
 def write_image(path, bgra):

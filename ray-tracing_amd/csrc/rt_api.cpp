@@ -39,14 +39,13 @@ struct FrameSet {
     hipStream_t flight_stream = nullptr;   // with frames in flight: a stream with a hardware queue of its own (rt_set_frames_in_flight)
     uint32_t coverage[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // what the buffers were last cleared for, compared field by field
     bool coverage_valid = false;
-    // path tracing: queues (2, ping-pong), the per-sample contribution planes of a batch of samples, hit records.  Sets 0 and
+    // path tracing: queues (2, ping-pong) and the per-sample contribution planes of a batch of samples.  Sets 0 and
     // 1 only (RT_PATH_SETS): a path-traced frame's tracing overlaps with the frame before it, its additions to the ONE
     // accumulation buffer wait for that frame's (rt_render)
     QueueMem q[2];
     size_t q_capacity = 0;
     float *d_contrib = nullptr;
     uint32_t contrib_planes = 0;
-    float *d_hits = nullptr;              // one 16-B hit record per queued path (k_path_trace -> k_path_shade)
     uint8_t *d_bgra = nullptr;            // rt_present_async: this set's encoded frame
     hipEvent_t ev_present = nullptr;      // ... and the arrival of its copy on the host
     bool present_pending = false;
@@ -206,7 +205,6 @@ void free_frame(rt_ctx *c) {
         }
         f.q_capacity = 0;
         p = f.d_contrib; free_dev(p); f.d_contrib = nullptr; f.contrib_planes = 0;
-        p = f.d_hits; free_dev(p); f.d_hits = nullptr;
         p = f.d_bgra; free_dev(p); f.d_bgra = nullptr;
         f.present_pending = false;
     }
@@ -270,12 +268,10 @@ int ensure_queues(rt_ctx *c, FrameSet &f, uint32_t batch) {
             p = f.q[i].u; free_dev(p); f.q[i].u = nullptr;
         }
         f.q_capacity = 0;
-        { void *p = f.d_hits; free_dev(p); f.d_hits = nullptr; }
         for (int i = 0; i < 2; ++i) {
             HIPCHK(c, hipMalloc((void **)&f.q[i].f, need * 9 * sizeof(float)));
             HIPCHK(c, hipMalloc((void **)&f.q[i].u, need * 2 * sizeof(uint32_t)));
         }
-        HIPCHK(c, hipMalloc((void **)&f.d_hits, need * 16));
         f.q_capacity = need;
     }
     if (f.contrib_planes < batch || !f.d_contrib) {
@@ -345,14 +341,7 @@ int rt_create(int device_ordinal, rt_ctx **out) {
         c->tune.uni_min = env("RT_TUNE_UNI_MIN", 16, 1, 65);
         c->tune.wide_vote_node = env("RT_TUNE_WIDE_VOTE_NODE", 3, 1, 64);
         c->tune.wide_vote_tri = env("RT_TUNE_WIDE_VOTE_TRI", 1, 1, 64);
-        c->tune.pool_dep = env("RT_TUNE_POOL_DEP", 0, 0, 32);
-        c->tune.pool_pick = env("RT_TUNE_POOL_PICK", 40, 1, 64);
-        c->tune.pool_drain = env("RT_TUNE_POOL_DRAIN", 0, 0, 1);
         c->tune.stream_waves = env("RT_TUNE_STREAM_WAVES", 0, 0, 8);
-        c->tune.path_split = env("RT_TUNE_PATH_SPLIT", 0, 0, 1);
-        c->tune.path_refill_min = env("RT_TUNE_PATH_REFILL_MIN", 16, 1, 64);
-        c->tune.path_sort = env("RT_TUNE_PATH_SORT", 0, 0, 6);
-        c->tune.path_sort_key = env("RT_TUNE_PATH_SORT_KEY", 0, 0, 1);
         c->tune_wide = env("RT_TUNE_WIDE", 1, 0, 1);
         c->tune_flight_prio = env("RT_TUNE_FLIGHT_PRIO", 0, 0, 1);
         c->tune_sample_batch = env("RT_TUNE_SAMPLE_BATCH", 16, 1, 16);
@@ -994,7 +983,6 @@ struct RenderTargets {
     unsigned long long *cnt;       // counters + work-queue heads (RT_CNT_N words)
     RtPathQueue qa, qb;            // path queues, capacity q_cap paths each
     float *contrib;                // per-sample contribution planes: max_batch planes of n_px float4
-    float *hits;                   // one float4 per queued path
     size_t q_cap;
     uint32_t max_batch;            // most samples of a pixel traced per launch (16, 4 or 1)
 };
@@ -1075,17 +1063,10 @@ static int launch_frame(rt_ctx *c, const rt_render_params &P, const RtShardDev &
             int in = RT_CNT_QUEUE_A, out = RT_CNT_QUEUE_B;
             for (uint32_t seg = 1; seg < P.max_segments; ++seg) {
                 HIPCHK(c, hipMemsetAsync(T.cnt + out, 0, sizeof(unsigned long long), c->stream));
-                // (an empty tree has nothing to walk: k_path_trace would hand out no path and leave the hit records unwritten -- the fused kernel ends such paths itself)
-                const bool split = c->tune.path_split && c->S.n_nodes != 0u && !(P.flags & (RT_FLAG_BRUTE_FORCE | RT_FLAG_STATIC_GRID));
-                if (split)
-                    HIPCHK(c, rtk_launch_path_trace_shade(c->stream, c->S, P.flags, cap, seg + 1 == P.max_segments, T.contrib, (uint32_t)c->n_px,
-                                                          in == RT_CNT_QUEUE_A ? T.qa : T.qb, T.hits, in == RT_CNT_QUEUE_A ? T.qb : T.qa,
-                                                          T.cnt, in, out, c->tune));
-                else
-                    HIPCHK(c, rtk_launch_path_bounce(c->stream, c->S, P.flags, cap, seg + 1 == P.max_segments, T.contrib, (uint32_t)c->n_px,
-                                                     in == RT_CNT_QUEUE_A ? T.qa : T.qb, in == RT_CNT_QUEUE_A ? T.qb : T.qa,
-                                                     T.cnt, in, out, c->tune));
-                launches += split ? 2u : 1u;
+                HIPCHK(c, rtk_launch_path_bounce(c->stream, c->S, P.flags, cap, seg + 1 == P.max_segments, T.contrib, (uint32_t)c->n_px,
+                                                 in == RT_CNT_QUEUE_A ? T.qa : T.qb, in == RT_CNT_QUEUE_A ? T.qb : T.qa,
+                                                 T.cnt, in, out, c->tune));
+                ++launches;
                 int tmp = in; in = out; out = tmp;
             }
             if (s == 0) {
@@ -1112,7 +1093,7 @@ int rt_render(rt_ctx *c, const rt_render_params *params) {
 
     // Frames in flight: frames take the sets in turn (each set has its own stream, so frame k + 1 fills the compute units
     // frame k's last regions leave idle).  Path-traced frames alternate between the first two sets only (their queues are
-    // large: 120 B per path; two in flight give what there is to gain, tools/path_two_contexts.py) and share ONE
+    // large: 104 B per path; two in flight give what there is to gain, tools/path_two_contexts.py) and share ONE
     // accumulation buffer: a frame's tracing overlaps with the frame before it, its additions wait for that frame's end.
     const bool path_frame = (P.flags & RT_FLAG_PATH_TRACE) != 0;
     if (c->n_sets > 1) select_set(c, (c->cur_set + 1) % (path_frame ? std::min(c->n_sets, RT_PATH_SETS) : c->n_sets));
@@ -1139,7 +1120,6 @@ int rt_render(rt_ctx *c, const rt_render_params *params) {
         T.max_batch = std::min(c->tune_sample_batch, F.contrib_planes);
         T.qa = queue_view(F.q[0], F.q_capacity); T.qb = queue_view(F.q[1], F.q_capacity);
         T.contrib = F.d_contrib;
-        T.hits = F.d_hits;
         // the running sums restart unless asked to go on -- and also when the camera or the geometry moved or the coverage
         // is not the one they were started under (intent of src/scene.rs:94-96); the clear is enqueued by launch_frame,
         // behind the frame before this one
@@ -1185,7 +1165,7 @@ int rt_render(rt_ctx *c, const rt_render_params *params) {
 // up once (c->static_scratch).  No hipMalloc / hipFree / hipEventCreate on this path, first call included.
 namespace {
 constexpr size_t kStaticCntBytes = 4096;                                   // RT_CNT_N * 8 = 1152 B, rounded up
-constexpr size_t kStaticPathBytesPerPx = 2 * 11 * 4 + 16 + 16;             // two queues of 11 dwords + one float4 plane + one hit record
+constexpr size_t kStaticPathBytesPerPx = 2 * 11 * 4 + 16;                  // two queues of 11 dwords + one float4 contribution plane
 constexpr size_t kStaticAlignSlack = 16 * 256;                             // every sub-buffer starts on a 256-B boundary
 constexpr size_t kStaticMaxPathPx = (RT_STATIC_SCRATCH_BYTES - kStaticCntBytes - kStaticAlignSlack) / kStaticPathBytesPerPx;
 static_assert(kStaticMaxPathPx == RT_STATIC_MAX_PATH_PIXELS, "include/rt_amd.h documents this limit");
@@ -1237,7 +1217,6 @@ int rt_render_static(rt_ctx *c, const rt_render_params *params, void *d_radiance
         QueueMem q[2];
         for (int i = 0; i < 2; ++i) { q[i].f = (float *)take(c->n_px * 9 * 4); q[i].u = (uint32_t *)take(c->n_px * 2 * 4); }
         T.contrib = (float *)take(c->n_px * 16);
-        T.hits = (float *)take(c->n_px * 16);
         if (off > RT_STATIC_SCRATCH_BYTES) return fail(c, RT_ERR_ARG, "rt_render_static: frame does not fit the static scratch array");
         T.qa = queue_view(q[0], c->n_px); T.qb = queue_view(q[1], c->n_px);
         T.q_cap = c->n_px; T.max_batch = 1;               // one sample per launch: same sums, bit for bit

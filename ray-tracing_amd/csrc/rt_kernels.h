@@ -24,11 +24,7 @@ struct RtTune {
     uint32_t vote_node, vote_tri;   // relative issue cost of a node step / a triangle step (phase vote)
     uint32_t uni_min;          // lanes that must share one node for the scalar node fetch (65 = never)
     uint32_t wide_vote_node, wide_vote_tri;   // the same vote weights when the 4-wide tree is walked
-    uint32_t pool_dep, pool_pick, pool_drain;   // k_stream's tail pool: deposit at <= pool_dep unfinished rays (0 = off), pick up at >= pool_pick pooled rays, pool_drain: deposit at the frame's end too
     uint32_t stream_waves;     // k_stream build: 0 = by frames in flight (8 waves per SIMD with three or more, else 7), 7 or 8 = that one
-    uint32_t path_split;       // bounce segments as k_path_trace + k_path_shade (1) or as k_path_bounce (0)
-    uint32_t path_sort, path_sort_key;   // k_path_bounce_sorted: 256-path chunks a block regroups by direction (0 = off), key (0 octant, 1 octant x major axis)
-    uint32_t path_refill_min;  // k_path_trace: ended rays in a wave that trigger a refill
 };
 hipError_t rtk_launch_primary(hipStream_t st, const RtSceneDev &S, const RtViewDev &V, const RtShardDev &sh,
                               uint32_t flags, float *rgba, uint32_t *prim, float *t,
@@ -46,13 +42,6 @@ hipError_t rtk_launch_path_start(hipStream_t st, const RtSceneDev &S, const RtVi
 hipError_t rtk_launch_path_bounce(hipStream_t st, const RtSceneDev &S, uint32_t flags, uint32_t capacity,
                                   int is_last, float *contrib, uint32_t n_px, RtPathQueue qin, RtPathQueue qout,
                                   unsigned long long *counters, int qin_counter, int qout_counter, const RtTune &tune);
-
-// The same segment as two launches (round 2): a persistent traversal kernel whose lanes are refilled from the queue as their
-// rays end, writing one 16-B hit record per queued path into `hits` (capacity floats x 4), then a full-lane scatter /
-// compaction kernel.  tune.path_refill_min = ended rays in a wave that trigger a refill.
-hipError_t rtk_launch_path_trace_shade(hipStream_t st, const RtSceneDev &S, uint32_t flags, uint32_t capacity, int is_last, float *contrib,
-                                       uint32_t n_px, RtPathQueue qin, float *hits, RtPathQueue qout, unsigned long long *counters,
-                                       int qin_counter, int qout_counter, const RtTune &tune);
 
 // f1: refit one tree level (nodes listed in level_nodes) from the vertices now in `verts`; leaf records re-baked.
 hipError_t rtk_launch_refit_level(hipStream_t st, RtBvhNode *nodes, RtTriRecord *recs, const rt_triangle *tris,

@@ -257,6 +257,76 @@ __device__ __forceinline__ void wide_decide(Q q0, Q q1, Q q2, Q q3, f3 o, f3 inv
     else cur = stack_pop(sp, stk, ovf);
 }
 
+// ---- the voted trip: ONE source for the loop body of every per-lane traversal (traverse<> and stream_body; round 3) --------
+// Every trip the wave VOTES: either every lane that holds an inner node takes one node step (one 64-B fetch; wide tree: four
+// quantised slab tests, binary tree: two), or every lane that holds a leaf tests ONE record of it -- whichever serves more
+// lanes per instruction issued (n_node * VOTE_TRI >= n_leaf * VOTE_NODE picks the node step).  All loop control is
+// wave-uniform.  Rounds 1 and 2 kept copies of this body in traverse<>, in k_stream and in a third kernel; a shared FUNCTION
+// was tried and cost the path kernels registers, so the shared source is a macro: expanded in place, it
+// compiles to what the copies compiled to.  Parameters: the tree (NODES: 64-B nodes of the kind WIDE_ says, RECS, MESHES),
+// FLAGS, compile-time WIDE_ / COUNT_ / UNIFORM_ (UNIFORM_: when every lane that takes the node step holds the SAME node --
+// 22-79 % of the node trips, the top of the tree walked in lockstep -- ONE scalar load brings it into SGPRs for the whole
+// wave instead of four vector loads per lane; only k_stream has the SGPRs to spare), the lane's ray (O, D, INV), its closest
+// hit so far (T, HU, HV, SEQ, REC), its place in the tree (CUR, SP, STK, OVF), ANY_ (any accepted hit ends the ray), the
+// wave's lane count N_ALL and ended-lane count N_DONE (read; the caller recounts after the trip), the vote weights, UNI_MIN,
+// the counters C and the lane id LANE.
+#define RT_VOTED_TRIP(NODES, RECS, MESHES, FLAGS, WIDE_, COUNT_, UNIFORM_, O, D, INV, T, HU, HV, SEQ, REC, CUR, SP, STK, OVF, ANY_, N_ALL, N_DONE, VOTE_NODE, VOTE_TRI, UNI_MIN, C, LANE) \
+    { \
+        const unsigned long long m_node_ = __ballot((CUR) >= 0); \
+        const uint32_t n_node_ = (uint32_t)__builtin_popcountll(m_node_); \
+        const uint32_t n_leaf_ = (N_ALL) - (N_DONE) - n_node_; \
+        if (n_node_ * (VOTE_TRI) >= n_leaf_ * (VOTE_NODE)) { \
+            bool uniform_ = false; \
+            int u0_ = 0; \
+            if (UNIFORM_) { \
+                u0_ = __builtin_amdgcn_readlane((CUR), __builtin_ctzll(m_node_)); \
+                uniform_ = n_node_ >= (UNI_MIN) && __ballot((CUR) >= 0 && (CUR) != u0_) == 0ull; \
+            } \
+            if (UNIFORM_ && uniform_) { \
+                typedef __attribute__((address_space(4))) const float cfloat_; \
+                cfloat_ *sp_ = (cfloat_ *)(const void *)((NODES) + u0_); \
+                q4 q0 = {sp_[0], sp_[1], sp_[2], sp_[3]}, q1 = {sp_[4], sp_[5], sp_[6], sp_[7]}; \
+                q4 q2 = {sp_[8], sp_[9], sp_[10], sp_[11]}, q3 = {sp_[12], sp_[13], sp_[14], sp_[15]}; \
+                if ((CUR) >= 0) { \
+                    if (COUNT_) { (C).nodes++; if ((LANE) == (uint32_t)__builtin_ctzll(m_node_)) { (C).wnodes++; (C).walive += n_node_ + n_leaf_; } } \
+                    if (WIDE_) wide_decide(q0, q1, q2, q3, (O), (INV), (T), (CUR), (SP), (STK), (OVF)); \
+                    else node_decide(q0, q1, q2, q3, (O), (INV), (T), (CUR), (SP), (STK), (OVF)); \
+                } \
+            } else if ((CUR) >= 0) { \
+                const float4 *p_ = reinterpret_cast<const float4 *>((NODES) + (CUR)); \
+                float4 q0 = p_[0], q1 = p_[1], q2 = p_[2], q3 = p_[3]; \
+                if (COUNT_) { (C).nodes++; if ((LANE) == (uint32_t)__builtin_ctzll(m_node_)) { (C).wnodes++; (C).walive += n_node_ + n_leaf_; } } \
+                if (WIDE_) wide_decide(q0, q1, q2, q3, (O), (INV), (T), (CUR), (SP), (STK), (OVF)); \
+                else node_decide(q0, q1, q2, q3, (O), (INV), (T), (CUR), (SP), (STK), (OVF)); \
+            } \
+        } else { \
+            if ((CUR) < 0 && (CUR) != RT_DONE) { \
+                if ((CUR) == RT_CHILD_NONE) (CUR) = stack_pop((SP), (STK), (OVF)); \
+                else { \
+                    const uint32_t code_ = (uint32_t)(~(CUR)); \
+                    const uint32_t first_ = code_ >> 3, left_ = code_ & 7u; \
+                    const float4 *r_ = reinterpret_cast<const float4 *>((RECS) + first_); \
+                    float4 r0 = r_[0], r1 = r_[1], r2 = r_[2]; \
+                    if (COUNT_) { (C).tris++; if ((LANE) == (uint32_t)__builtin_ctzll(__ballot(true))) (C).wtris++; } \
+                    float dst_, u_, v_; \
+                    bool ok_ = prim_test((O), (D), r0, r1, r2, dst_, u_, v_); \
+                    const uint32_t sq_ = __float_as_uint(r2.w); \
+                    ok_ = ok_ && (dst_ < (T) || (dst_ == (T) && sq_ < (SEQ))); \
+                    if (ok_ && !((FLAGS) & RT_FLAG_NO_MESH_CULL) && __float_as_uint(r2.z) != RT_REC_SPHERE) {   /* per-mesh AABB cull of wgsl:155 */ \
+                        const float4 *mp_ = reinterpret_cast<const float4 *>((MESHES) + __float_as_uint(r2.z)); \
+                        float4 m1 = mp_[1], m2 = mp_[2]; \
+                        ok_ = ray_aabb_ref((O), exact_inv<WIDE_>((INV), (D)), F3(m1.x, m1.y, m1.z), F3(m2.x, m2.y, m2.z)); \
+                        if (COUNT_) (C).meshes++; \
+                    } \
+                    if (ok_) { (T) = dst_; (SEQ) = sq_; (REC) = first_; (HU) = u_; (HV) = v_; }   /* tri / mesh: read back from the record when the ray ends */ \
+                    if (ok_ && (ANY_)) (CUR) = RT_DONE;                       /* shadow ray: any hit answers it */ \
+                    else if (left_ == 0u) (CUR) = stack_pop((SP), (STK), (OVF)); \
+                    else (CUR) = ~(int)(((first_ + 1u) << 3) | (left_ - 1u)); \
+                } \
+            } \
+        } \
+    }
+
 // ---- BVH traversal (build-side design; reference src/bvh.rs:1 is empty) ----------------------
 // Closest hit with the reference's tie rule restated order-independently: among equal t the
 // lowest position in the (mesh, triangle) loop order wins (ray_tracing.wgsl:164).
@@ -289,45 +359,10 @@ __device__ __forceinline__ void traverse(const RtSceneDev &S, f3 o, f3 d, uint32
     uint32_t n_done = (uint32_t)__builtin_popcountll(__ballot(cur == RT_DONE));
     if (n_done == n_all) return;
     uint32_t rec = 0xFFFFFFFFu;           // the accepted record: one register instead of hit flag + tri + mesh
+    const uint32_t lane = threadIdx.x & 63u;
     do {
-        const unsigned long long m_node = __ballot(cur >= 0);
-        const uint32_t n_node = (uint32_t)__builtin_popcountll(m_node);
-        const uint32_t n_leaf = n_all - n_done - n_node;
-        if (n_node * vote_tri >= n_leaf * vote_node) {
-            if (cur >= 0) {
-                const float4 *p = reinterpret_cast<const float4 *>(nodes + cur);
-                float4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3];
-                if (COUNT) { c.nodes++; if ((threadIdx.x & 63u) == (uint32_t)__builtin_ctzll(m_node)) { c.wnodes++; c.walive += n_node + n_leaf; } }
-                if (WIDE) wide_decide(q0, q1, q2, q3, o, inv, h.t, cur, sp, stk, ovf);
-                else node_decide(q0, q1, q2, q3, o, inv, h.t, cur, sp, stk, ovf);
-            }
-        } else {
-            if (cur < 0 && cur != RT_DONE) {
-                if (cur == RT_CHILD_NONE) cur = stack_pop(sp, stk, ovf);
-                else {
-                    uint32_t code = (uint32_t)(~cur);
-                    uint32_t first = code >> 3, left = code & 7u;
-                    const float4 *r = reinterpret_cast<const float4 *>(S.recs + first);
-                    float4 r0 = r[0], r1 = r[1], r2 = r[2];
-                    if (COUNT) { c.tris++; if ((threadIdx.x & 63u) == (uint32_t)__builtin_ctzll(__ballot(true))) c.wtris++; }
-                    float dst, u, v;
-                    bool ok = prim_test(o, d, r0, r1, r2, dst, u, v);
-                    uint32_t seq = __float_as_uint(r2.w);
-                    ok = ok && (dst < h.t || (dst == h.t && seq < h.seq));
-                    uint32_t mesh = __float_as_uint(r2.z);
-                    if (ok && !(flags & RT_FLAG_NO_MESH_CULL) && mesh != RT_REC_SPHERE) {   // per-mesh AABB cull of wgsl:155
-                        const float4 *mp = reinterpret_cast<const float4 *>(S.meshes + mesh);
-                        float4 m1 = mp[1], m2 = mp[2];
-                        ok = ray_aabb_ref(o, exact_inv<WIDE>(inv, d), F3(m1.x, m1.y, m1.z), F3(m2.x, m2.y, m2.z));
-                        if (COUNT) c.meshes++;
-                    }
-                    if (ok) { h.t = dst; h.u = u; h.v = v; h.seq = seq; rec = first; }   // tri / mesh: read back from the record below
-                    if (ok && ANY) cur = RT_DONE;
-                    else if (left == 0u) cur = stack_pop(sp, stk, ovf);
-                    else cur = ~(int)(((first + 1u) << 3) | (left - 1u));
-                }
-            }
-        }
+        RT_VOTED_TRIP(nodes, S.recs, S.meshes, flags, WIDE, COUNT, false, o, d, inv, h.t, h.u, h.v, h.seq, rec, cur, sp, stk, ovf, ANY,
+                      n_all, n_done, vote_node, vote_tri, 65u, c, lane)
         n_done = (uint32_t)__builtin_popcountll(__ballot(cur == RT_DONE));
     } while (n_done != n_all);
     if (rec != 0xFFFFFFFFu) {
@@ -668,32 +703,16 @@ __device__ __forceinline__ bool pixel_of_region(const RtViewDev &V, const RtShar
     return xx < V.vw && yy < V.vh;
 }
 
-// ---- the block's tail pool (round 2) ------------------------------------------------------------------------------
-// A wave lives as long as its longest ray: 42 % of the lane slots of a node trip belonged to rays that had already
-// ended, and about half of a wave's trips ran with <= 16 of its 64 rays unfinished.  Refilling the freed lanes with
-// fresh rays was measured again and again to lose more than it gains (fresh rays walk the top of the tree while the
-// stragglers are deep in it: no shared fetches, split votes).  The pool re-packs rays of the SAME kind instead: a wave
-// that is down to its last <= pool_dep rays DEPOSITS them -- ray, closest hit so far, current node and the stack -- in a
-// small LDS pool of its block and takes a fresh 8x8 region with all 64 lanes; a wave that is out of work takes
-// up to 64 pooled rays at once (stragglers of the block's four waves, i.e. of neighbouring regions) and walks them
-// as one full wave.  Fresh waves stay all-fresh, straggler waves are all stragglers, and the stragglers run with
-// several times the lane occupancy.  A ray's own sequence of steps does not change (only which lane executes them), so
-// results and counted visits are identical.
-// Protocol (all in LDS, one lock per block): deposits and pick-ups copy under the lock; s_running counts the block's
-// waves that have not left yet; a wave deposits only while another wave is still there to pick up (s_running >= 2) and
-// leaves only after looking at the pool under the lock -- the last wave of a block (s_running == 1) takes what is
-// there, so no ray is ever left behind and every wave reaches its exit.
-#ifndef RT_POOL
-#define RT_POOL 64           // pooled rays per block
-#endif
+// (Round 2 also carried a block TAIL POOL here -- a wave down to its last <= 16 rays deposited them, stack and all, in an LDS
+// pool of its block and took a fresh region; an idle wave took up to 64 pooled stragglers at once.  Frames and counted visits
+// identical, VALU instructions -12 %, lanes active 0.47 -> 0.56, and the frame +3 % one at a time, +13 % with frames in flight
+// (24.5 KB of LDS and 88 VGPRs: 5 waves per SIMD).  Measured, kept as an opt-in for a round, removed in round 3; the code is
+// in the history at fa55bd4, the measurements in profiles/r2/ab_pool_*.txt and DESIGN.md section 4.1.)
 struct RtStreamTune {
     uint32_t refill_min, finish_min, vote_node, vote_tri, uni_min;
-    uint32_t pool_dep;       // a wave with <= this many unfinished rays deposits them (0: the pool is off)
-    uint32_t pool_pick;      // an idle wave takes pooled rays before a fresh region once this many wait
-    uint32_t pool_drain;     // deposits also once the work queues are empty (the frame's end): 0 / 1
 };
 
-template <bool COUNT, bool WIDE, bool POOL>
+template <bool COUNT, bool WIDE>
 __device__ __forceinline__ void stream_body(
     const RtSceneDev &S_, const RtViewDev &V_, const RtShardDev &sh_, uint32_t flags, const RtStreamTune tn,
     float4 *__restrict__ rgba, uint32_t *__restrict__ prim, float *__restrict__ tout, unsigned long long *__restrict__ counters) {
@@ -702,13 +721,7 @@ __device__ __forceinline__ void stream_body(
     __shared__ RtSceneDev S;
     __shared__ RtViewDev V;
     __shared__ RtShardDev sh;
-    // the tail pool: SoA, slot-major inside a plane (consecutive lanes -> consecutive banks)
-    constexpr uint32_t NP = POOL ? RT_POOL : 1;     // the kernel built without the pool keeps no LDS for it
-    __shared__ float s_pool_f[9][NP];               // o.xyz d.xyz t hu hv
-    __shared__ uint32_t s_pool_u[6][NP];            // seq rec cur sp idx state
-    __shared__ int s_pool_stk[RT_STACK_LDS][NP];
-    __shared__ uint32_t s_pool_n, s_pool_lock, s_running;
-    if (threadIdx.x == 0) { S = S_; V = V_; sh = sh_; s_pool_n = 0u; s_pool_lock = 0u; s_running = RT_BLOCK / 64u; }
+    if (threadIdx.x == 0) { S = S_; V = V_; sh = sh_; }
     __syncthreads();
     lds_int *stk = (lds_int *)(s_stack + threadIdx.x);
     int ovf_mem[RT_STACK_OVF];
@@ -725,8 +738,6 @@ __device__ __forceinline__ void stream_body(
     // wave-uniform work-source state
     uint32_t reg_q = 0, reg_r = 0, reg_next = RT_REGION_PX;  // the wave's region and its next pixel
     uint32_t qoff = 0u;                                     // queues found empty so far (8 = all)
-    const uint32_t pool_dep = POOL ? tn.pool_dep : 0u;
-    uint32_t dep_thresh = pool_dep;                         // unfinished rays at or below which the wave tries to deposit
     Cnt c; c.nodes = 0; c.tris = 0; c.meshes = 0; c.wnodes = 0; c.wtris = 0; c.walive = 0;
     uint32_t n_primary = 0, n_shadow = 0;
     // per-lane ray
@@ -742,43 +753,6 @@ __device__ __forceinline__ void stream_body(
 #ifdef RT_DEBUG_TIMELINE
     const unsigned long long dbg_t0 = wall_clock64();
 #endif
-    // the block's lock: taken by one lane for the wave (wave-uniform control flow around it), released after the wave's LDS
-    // writes have landed
-    auto pool_lock = [&]() {
-        if (lane == 0u) {
-            while (__hip_atomic_exchange(&s_pool_lock, 1u, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != 0u) __builtin_amdgcn_s_sleep(2);
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        __builtin_amdgcn_wave_barrier();
-    };
-    auto pool_unlock = [&]() {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_wave_barrier();
-        if (lane == 0u) __hip_atomic_store(&s_pool_lock, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-    };
-    auto lds_u32 = [&](const uint32_t *p) {   // a wave-uniform read of a block variable (not cached in a register)
-        return (uint32_t)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
-    };
-    // idle lanes take up to n_take pooled rays (the newest ones); call with the lock held
-    auto pool_take = [&](uint32_t n_have, uint32_t n_take, unsigned long long idle) {
-        const uint32_t r = (uint32_t)__builtin_popcountll(idle & below);
-        const bool mine = state == 0 && r < n_take;
-        const uint32_t slot = n_have - n_take + (mine ? r : 0u);
-        if (mine) {
-            o = F3(s_pool_f[0][slot], s_pool_f[1][slot], s_pool_f[2][slot]);
-            d = F3(s_pool_f[3][slot], s_pool_f[4][slot], s_pool_f[5][slot]);
-            t = s_pool_f[6][slot]; hu = s_pool_f[7][slot]; hv = s_pool_f[8][slot];
-            seq = s_pool_u[0][slot]; rec = s_pool_u[1][slot]; cur = (int)s_pool_u[2][slot]; sp = (int)s_pool_u[3][slot];
-            idx = s_pool_u[4][slot]; state = (int)s_pool_u[5][slot];
-            inv = ray_inv<WIDE>(d);
-        }
-        const int top = mine ? sp : 0;
-        for (int l = 0; l < RT_STACK_LDS; ++l) {
-            if (__ballot(l < top) == 0ull) break;
-            if (l < top) stk[l * RT_BLOCK] = s_pool_stk[l][slot];
-        }
-        if (lane == 0u) __hip_atomic_store(&s_pool_n, n_have - n_take, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    };
     for (;;) {
         // ================= service: runs when the hot loop below asks for it =================================
         // What the service code reads of the scene / view / shard descriptions it reads from LDS HERE, every time: without
@@ -818,54 +792,11 @@ __device__ __forceinline__ void stream_body(
             state = 0;
         }
         bool more = qoff < 8u || reg_next < RT_REGION_PX;
-        // ---- 1b. a wave down to its last few rays deposits them in the block's pool ---------------------------------
-        bool deposited = false;
-        if (POOL && pool_dep != 0u) {
-            const unsigned long long livem = __ballot(cur != RT_DONE);
-            const uint32_t n_l = (uint32_t)__builtin_popcountll(livem);
-            if (n_l != 0u && n_l <= dep_thresh) {
-                if (__ballot(cur != RT_DONE && sp > RT_STACK_LDS) == 0ull) {      // the private part of a stack does not travel
-                    pool_lock();
-                    const uint32_t have = lds_u32(&s_pool_n), running = lds_u32(&s_running);
-                    if (have + n_l <= NP && running >= 2u && (more || tn.pool_drain != 0u)) {
-                        const bool live = cur != RT_DONE;
-                        const uint32_t slot = have + (uint32_t)__builtin_popcountll(livem & below);
-                        if (live) {
-                            s_pool_f[0][slot] = o.x; s_pool_f[1][slot] = o.y; s_pool_f[2][slot] = o.z;
-                            s_pool_f[3][slot] = d.x; s_pool_f[4][slot] = d.y; s_pool_f[5][slot] = d.z;
-                            s_pool_f[6][slot] = t; s_pool_f[7][slot] = hu; s_pool_f[8][slot] = hv;
-                            s_pool_u[0][slot] = seq; s_pool_u[1][slot] = rec; s_pool_u[2][slot] = (uint32_t)cur; s_pool_u[3][slot] = (uint32_t)sp;
-                            s_pool_u[4][slot] = idx; s_pool_u[5][slot] = (uint32_t)state;
-                        }
-                        const int top = live ? sp : 0;
-                        for (int l = 0; l < RT_STACK_LDS; ++l) {
-                            if (__ballot(l < top) == 0ull) break;
-                            if (l < top) s_pool_stk[l][slot] = stk[l * RT_BLOCK];
-                        }
-                        if (live) { cur = RT_DONE; state = 0; sp = 0; }
-                        if (lane == 0u) __hip_atomic_store(&s_pool_n, have + n_l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        deposited = true;
-                    }
-                    pool_unlock();
-                }
-                // not deposited (deep stacks, a full pool, the block's last wave): try again when half of these rays are left
-                if (!deposited) dep_thresh = n_l >> 1;
-            }
-        }
         // ---- 2. idle lanes take new work -------------------------------------------------------------------------
         unsigned long long idle = __ballot(state == 0);
         {
-            // pooled stragglers first when enough of them wait (a full wave's worth of the same kind of ray) ...
-            if (POOL && pool_dep != 0u && idle == ~0ull && more && lds_u32(&s_pool_n) >= tn.pool_pick) {
-                pool_lock();
-                const uint32_t have = lds_u32(&s_pool_n);
-                if (have >= tn.pool_pick) pool_take(have, have < 64u ? have : 64u, idle);
-                pool_unlock();
-                idle = __ballot(state == 0);
-                dep_thresh = pool_dep;
-            }
-            // ... else the wave's region; a used-up region is replaced from the XCD's queue (one atomic per 64
-            // pixels), an empty queue by the next XCD's
+            // the wave's region; a used-up region is replaced from the XCD's queue (one atomic per 64 pixels), an empty queue
+            // by the next XCD's
             const bool all_idle = idle == ~0ull;
             const uint32_t rpt = (sh.tile >> 4) * (sh.tile >> 4) * 4u;   // 8x8 regions per shard tile
             while (idle && ((uint32_t)__builtin_popcountll(idle) >= refill_min || all_idle)) {
@@ -908,31 +839,9 @@ __device__ __forceinline__ void stream_body(
                 }
                 reg_next += (uint32_t)__builtin_popcountll(idle);   // pixels outside the image are skipped
                 idle = __ballot(state == 0);
-                dep_thresh = pool_dep;
             }
             more = qoff < 8u || reg_next < RT_REGION_PX;
-            // the queues are empty: idle lanes take whatever the pool holds (the frame's end merges the block's tails) --
-            // except right after this wave's own deposit, which is for the block's other waves
-            if (POOL && pool_dep != 0u && !more && idle != 0ull && !deposited && lds_u32(&s_pool_n) != 0u) {
-                pool_lock();
-                const uint32_t have = lds_u32(&s_pool_n), n_idle_l = (uint32_t)__builtin_popcountll(idle);
-                if (have != 0u) pool_take(have, have < n_idle_l ? have : n_idle_l, idle);
-                pool_unlock();
-                idle = __ballot(state == 0);
-                dep_thresh = pool_dep;
-            }
-            if (idle == ~0ull && !more) {
-                // nothing in flight, no regions left: leave -- unless this is the block's last wave and rays wait in the pool
-                if (!POOL || pool_dep == 0u) break;
-                bool leave = true;
-                pool_lock();
-                const uint32_t have = lds_u32(&s_pool_n), running = lds_u32(&s_running);
-                if (have != 0u && running <= 1u) { pool_take(have, have < 64u ? have : 64u, idle); leave = false; }
-                else if (lane == 0u) __hip_atomic_store(&s_running, running - 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                pool_unlock();
-                if (leave) break;
-                dep_thresh = pool_dep;
-            }
+            if (idle == ~0ull && !more) break;                // nothing in flight, no regions left: leave
         }
         if (__ballot(cur != RT_DONE) == 0ull) continue;   // only ended rays (e.g. an empty scene): service again
         // ================= hot loop: one voted step per trip, until the wave needs service ========================
@@ -941,59 +850,8 @@ __device__ __forceinline__ void stream_body(
         const uint32_t n_idle = (uint32_t)__builtin_popcountll(__ballot(state == 0));
         uint32_t n_done = (uint32_t)__builtin_popcountll(__ballot(cur == RT_DONE)), n_pend, n_live;
         do {
-            // ---- vote: one node step or one triangle step for the whole wave -----------------------------------
-            const unsigned long long m_node = __ballot(cur >= 0);
-            const uint32_t n_node = (uint32_t)__builtin_popcountll(m_node);
-            const uint32_t n_leaf = 64u - n_done - n_node;
-            if (n_node * vote_tri >= n_leaf * vote_node) {
-                // Every lane that takes this step holds the SAME node in 22-79 % of the node trips (the top of the tree,
-                // walked in lockstep): then ONE scalar load brings the node into SGPRs for the whole wave instead of four
-                // vector loads per lane -- the vector-memory front end is as busy as the VALU in this kernel.
-                const int u0 = __builtin_amdgcn_readlane(cur, __builtin_ctzll(m_node));
-                const bool uniform = n_node >= uni_min && __ballot(cur >= 0 && cur != u0) == 0ull;
-                if (uniform) {
-                    typedef __attribute__((address_space(4))) const float cfloat;
-                    cfloat *sp_ = (cfloat *)(const void *)(nodes + u0);
-                    q4 q0 = {sp_[0], sp_[1], sp_[2], sp_[3]}, q1 = {sp_[4], sp_[5], sp_[6], sp_[7]};
-                    q4 q2 = {sp_[8], sp_[9], sp_[10], sp_[11]}, q3 = {sp_[12], sp_[13], sp_[14], sp_[15]};
-                    if (cur >= 0) {
-                        if (COUNT) { c.nodes++; if (lane == (uint32_t)__builtin_ctzll(m_node)) { c.wnodes++; c.walive += n_node + n_leaf; } }
-                        if (WIDE) wide_decide(q0, q1, q2, q3, o, inv, t, cur, sp, stk, ovf);
-                        else node_decide(q0, q1, q2, q3, o, inv, t, cur, sp, stk, ovf);
-                    }
-                } else if (cur >= 0) {
-                    const float4 *p = reinterpret_cast<const float4 *>(nodes + cur);
-                    float4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3];
-                    if (COUNT) { c.nodes++; if (lane == (uint32_t)__builtin_ctzll(m_node)) { c.wnodes++; c.walive += n_node + n_leaf; } }
-                    if (WIDE) wide_decide(q0, q1, q2, q3, o, inv, t, cur, sp, stk, ovf);
-                    else node_decide(q0, q1, q2, q3, o, inv, t, cur, sp, stk, ovf);
-                }
-            } else {
-                if (cur < 0 && cur != RT_DONE) {
-                    if (cur == RT_CHILD_NONE) cur = stack_pop(sp, stk, ovf);
-                    else {
-                        uint32_t code = (uint32_t)(~cur);
-                        uint32_t first = code >> 3, left = code & 7u;
-                        const float4 *r = reinterpret_cast<const float4 *>(recs + first);
-                        float4 r0 = r[0], r1 = r[1], r2 = r[2];
-                        if (COUNT) { c.tris++; if (lane == (uint32_t)__builtin_ctzll(__ballot(true))) c.wtris++; }
-                        float dst, u, v;
-                        bool ok = prim_test(o, d, r0, r1, r2, dst, u, v);
-                        uint32_t sq = __float_as_uint(r2.w);
-                        ok = ok && (dst < t || (dst == t && sq < seq));
-                        if (ok && !(flags & RT_FLAG_NO_MESH_CULL) && __float_as_uint(r2.z) != RT_REC_SPHERE) {   // per-mesh AABB cull of wgsl:155
-                            const float4 *mp = reinterpret_cast<const float4 *>(meshes + __float_as_uint(r2.z));
-                            float4 m1 = mp[1], m2 = mp[2];
-                            ok = ray_aabb_ref(o, exact_inv<WIDE>(inv, d), F3(m1.x, m1.y, m1.z), F3(m2.x, m2.y, m2.z));
-                            if (COUNT) c.meshes++;
-                        }
-                        if (ok) { t = dst; seq = sq; rec = first; hu = u; hv = v; }
-                        if (ok && any) cur = RT_DONE;                        // shadow ray: any hit answers it
-                        else if (left == 0u) cur = stack_pop(sp, stk, ovf);
-                        else cur = ~(int)(((first + 1u) << 3) | (left - 1u));
-                    }
-                }
-            }
+            RT_VOTED_TRIP(nodes, recs, meshes, flags, WIDE, COUNT, true, o, d, inv, t, hu, hv, seq, rec, cur, sp, stk, ovf, any,
+                          64u, n_done, vote_node, vote_tri, uni_min, c, lane)
             n_done = (uint32_t)__builtin_popcountll(__ballot(cur == RT_DONE));
             n_pend = n_done - n_idle;
             n_live = 64u - n_done;
@@ -1007,7 +865,7 @@ __device__ __forceinline__ void stream_body(
                 return;
             }
 #endif
-        } while (!(n_live <= dep_thresh || n_pend >= finish_min || (more && n_done >= refill_min)));
+        } while (!(n_live == 0u || n_pend >= finish_min || (more && n_done >= refill_min)));
     }
 #ifdef RT_DEBUG_TIMELINE     // debug builds only (tools/timeline.py): per-wave start / end times (100 MHz) over the hit-distance output
     if (lane == 0u) {
@@ -1034,11 +892,11 @@ __device__ __forceinline__ void stream_body(
 #ifndef RT_STREAM_WAVES
 #define RT_STREAM_WAVES RT_MIN_WAVES
 #endif
-template <bool COUNT, bool WIDE, bool POOL>
-__global__ __launch_bounds__(RT_BLOCK, POOL ? (RT_STREAM_WAVES < 5 ? RT_STREAM_WAVES : 5) : RT_STREAM_WAVES) void k_stream(   // the pool's LDS leaves room for 6 blocks per CU
+template <bool COUNT, bool WIDE>
+__global__ __launch_bounds__(RT_BLOCK, RT_STREAM_WAVES) void k_stream(
     RtSceneDev S_, RtViewDev V_, RtShardDev sh_, uint32_t flags, RtStreamTune tn, float4 *__restrict__ rgba, uint32_t *__restrict__ prim,
     float *__restrict__ tout, unsigned long long *__restrict__ counters) {
-    stream_body<COUNT, WIDE, POOL>(S_, V_, sh_, flags, tn, rgba, prim, tout, counters);
+    stream_body<COUNT, WIDE>(S_, V_, sh_, flags, tn, rgba, prim, tout, counters);
 }
 // The same kernel built for 8 waves per SIMD (64 VGPRs, 10 spilled): launched with three or more frames in flight, where the
 // chip never drains and one more wave per SIMD hides more of the gathers' latency than the spills cost -- bench scene, 4 in
@@ -1048,7 +906,7 @@ template <bool COUNT, bool WIDE>
 __global__ __launch_bounds__(RT_BLOCK, 8) void k_stream8(
     RtSceneDev S_, RtViewDev V_, RtShardDev sh_, uint32_t flags, RtStreamTune tn, float4 *__restrict__ rgba, uint32_t *__restrict__ prim,
     float *__restrict__ tout, unsigned long long *__restrict__ counters) {
-    stream_body<COUNT, WIDE, false>(S_, V_, sh_, flags, tn, rgba, prim, tout, counters);
+    stream_body<COUNT, WIDE>(S_, V_, sh_, flags, tn, rgba, prim, tout, counters);
 }
 
 // ---- A2 RNG: ray_tracing.wgsl:38-74 (integer core; deterministic log/cos) ------------------------
@@ -1281,250 +1139,10 @@ __global__ __launch_bounds__(RT_BLOCK, RT_MIN_WAVES) void k_path_bounce(RtSceneD
     }
 }
 
-// ---- bounce segments with the queue regrouped by ray direction (round 2) ------------------------------
-// A block takes sort_m x 256 consecutive queued paths (screen neighbours: the queue is in compaction order), counting-sorts
-// their indices in LDS by a direction key -- sign octant (8 bins) or octant x major axis (24 bins) -- and then walks them
-// 256 at a time in that order, so the 64 rays of a wave start from nearby points AND head the same way.  No extra pass over
-// the queue, no global atomics: the directions are read twice (the second time from the cache), the permutation lives in
-// LDS.  A path's arithmetic is unchanged; only which lanes share a wave changes, so the sums are bit-identical.
-#define RT_SORT_MAX_M 6u            // 2 x 6 x 256 x 2 B of LDS beside the stacks: still 7 blocks per CU
-#define RT_SORT_BINS 32u
-__device__ __forceinline__ uint32_t path_sort_key(float dx, float dy, float dz, uint32_t mode) {
-    const uint32_t oct = (dx < 0.0f ? 1u : 0u) | (dy < 0.0f ? 2u : 0u) | (dz < 0.0f ? 4u : 0u);
-    if (mode == 0u) return oct;
-    const float ax = fabsf(dx), ay = fabsf(dy), az = fabsf(dz);
-    const uint32_t major = (ax >= ay && ax >= az) ? 0u : (ay >= az ? 1u : 2u);
-    return oct * 3u + major;
-}
-template <bool COUNT>
-__global__ __launch_bounds__(RT_BLOCK, RT_MIN_WAVES) void k_path_bounce_sorted(RtSceneDev S, uint32_t flags, int is_last,
-                                                          float4 *__restrict__ contrib, uint32_t n_px, RtPathQueue qi, RtPathQueue qo,
-                                                          unsigned long long *__restrict__ counters, int qi_ctr,
-                                                          int qo_ctr, uint32_t sort_m, uint32_t sort_key) {
-    __shared__ int s_stack[RT_STACK_LDS * RT_BLOCK];
-    __shared__ uint16_t s_tmp[RT_SORT_MAX_M * RT_BLOCK];     // key << 11 | arrival rank within the key's bin (< 1536)
-    __shared__ uint16_t s_perm[RT_SORT_MAX_M * RT_BLOCK];    // sorted position -> index within the chunk
-    __shared__ uint32_t s_bin[64];
-    int *stk = s_stack + threadIdx.x;
-    const uint32_t n = (uint32_t)counters[qi_ctr];
-    const uint32_t chunk = RT_BLOCK * sort_m;
-    Cnt c; c.nodes = 0; c.tris = 0; c.meshes = 0; c.wnodes = 0; c.wtris = 0; c.walive = 0;
-    uint32_t n_bounce = 0;
-    for (uint32_t base = blockIdx.x * chunk; base < n; base += gridDim.x * chunk) {   // the trip count is the same for a whole block
-        const uint32_t cnt = n - base < chunk ? n - base : chunk;
-        if (threadIdx.x < 64u) s_bin[threadIdx.x] = 0u;
-        __syncthreads();
-        for (uint32_t j = threadIdx.x; j < cnt; j += RT_BLOCK) {
-            const uint32_t i = base + j;
-            const uint32_t key = path_sort_key(qi.dx[i], qi.dy[i], qi.dz[i], sort_key);
-            s_tmp[j] = (uint16_t)((key << 11) | atomicAdd(&s_bin[key], 1u));
-        }
-        __syncthreads();
-        if (threadIdx.x < 64u) {                             // exclusive prefix over the bins, one wave
-            const uint32_t v = s_bin[threadIdx.x];
-            uint32_t incl = v;
-            for (int ofs = 1; ofs < 64; ofs <<= 1) {
-                const uint32_t up = __shfl_up(incl, ofs);
-                if ((int)threadIdx.x >= ofs) incl += up;
-            }
-            s_bin[threadIdx.x] = incl - v;
-        }
-        __syncthreads();
-        for (uint32_t j = threadIdx.x; j < cnt; j += RT_BLOCK) {
-            const uint32_t e = s_tmp[j];
-            s_perm[s_bin[e >> 11] + (e & 0x7FFu)] = (uint16_t)j;
-        }
-        __syncthreads();
-        for (uint32_t j0 = 0; j0 < cnt; j0 += RT_BLOCK) {    // uniform per block: queue_slot's ballots see whole waves
-            const uint32_t j = j0 + threadIdx.x;
-            const bool active = j < cnt;
-            bool alive = false;
-            f3 o, d, col; uint32_t rng = 0, pixel = 0;
-            if (active) {
-                const uint32_t i = base + s_perm[j];
-                o = F3(qi.ox[i], qi.oy[i], qi.oz[i]);
-                d = F3(qi.dx[i], qi.dy[i], qi.dz[i]);
-                Hit h;
-                trace<false, COUNT>(S, o, d, flags, stk, h, c);
-                const uint32_t i2 = base + s_perm[j];        // re-read after the traversal (registers)
-                col = F3(qi.cr[i2], qi.cg[i2], qi.cb[i2]);
-                rng = qi.rng[i2]; pixel = qi.pixel[i2];
-                alive = path_scatter(S, h, o, d, col, rng, contrib + (size_t)(pixel >> RT_PATH_SLOT_SHIFT) * n_px + (pixel & RT_PATH_PIXEL_MASK)) && !is_last;
-                ++n_bounce;
-            }
-            uint32_t slot = queue_slot(counters + qo_ctr, alive);
-            if (alive) {
-                qo.ox[slot] = o.x; qo.oy[slot] = o.y; qo.oz[slot] = o.z;
-                qo.dx[slot] = d.x; qo.dy[slot] = d.y; qo.dz[slot] = d.z;
-                qo.cr[slot] = col.x; qo.cg[slot] = col.y; qo.cb[slot] = col.z;
-                qo.rng[slot] = rng; qo.pixel[slot] = pixel;
-            }
-        }
-    }
-    wave_sum(counters + RT_CNT_BOUNCE, n_bounce);
-    if (COUNT) {
-        wave_sum(counters + RT_CNT_NODES, c.nodes);
-        wave_sum(counters + RT_CNT_TRIS, c.tris);
-        wave_sum(counters + RT_CNT_MESH, c.meshes);
-        wave_sum(counters + RT_CNT_WNODE, c.wnodes);
-        wave_sum(counters + RT_CNT_WTRI, c.wtris);
-        wave_sum(counters + RT_CNT_WALIVE, c.walive);
-    }
-}
-
-// ---- bounce segments, split (round 2): k_path_trace walks, k_path_shade scatters -------------------------------------
-// k_path_bounce keeps a wave on its 64 paths until the LONGEST of their segments has ended (its VALU instructions run
-// with 36 % of the lanes; profiles/r2/pmc_path_*.txt), and every attempt to refill lanes inside it also ran the scatter
-// code -- three Box-Muller normals, ~400 instructions -- for a handful of lanes at a time.  Here the two halves of a segment
-// are separate launches: k_path_trace is a persistent kernel whose lanes are refilled from the queue as their rays end
-// (bounce rays are incoherent, there is no lockstep to lose, and a refill is six loads), and writes one 16-B hit record
-// per path; k_path_shade then reads queue + hit records with all lanes busy, scatters and compacts.  A path's arithmetic
-// is unchanged (the same traversal steps in the same order, the same path_scatter), so the sums are bit-identical; only
-// the ORDER of the next queue changes, which nothing depends on (one contribution slot per path).
-#define RT_TRACE_CHUNK 256u         // paths a wave takes per atomic on the work counter
-template <bool COUNT, bool WIDE>
-__global__ __launch_bounds__(RT_BLOCK, RT_MIN_WAVES) void k_path_trace(
-    const RtBvhNode *__restrict__ nodes_, const RtTriRecord *__restrict__ recs, const rt_mesh_info *__restrict__ meshes, uint32_t n_nodes,
-    uint32_t flags, RtPathQueue qi, float4 *__restrict__ hits, unsigned long long *__restrict__ counters, int qi_ctr,
-    uint32_t refill_min, uint32_t vote_node, uint32_t vote_tri) {
-    __shared__ int s_stack[RT_STACK_LDS * RT_BLOCK];
-    lds_int *stk = (lds_int *)(s_stack + threadIdx.x);
-    int ovf_mem[RT_STACK_OVF];
-    prv_int *ovf = (prv_int *)ovf_mem;
-    const RtBvhNode *const nodes = nodes_;
-    const uint32_t n = (uint32_t)counters[qi_ctr];
-    const uint32_t lane = threadIdx.x & 63u;
-    const unsigned long long below = (1ull << lane) - 1ull;
-    unsigned long long *work = counters + RT_CNT_WORK;
-    uint32_t chunk_next = 0u, chunk_end = 0u;      // wave-uniform: the wave's share of the queue not handed to a lane yet
-    bool more = n != 0u && n_nodes != 0u;
-    Cnt c; c.nodes = 0; c.tris = 0; c.meshes = 0; c.wnodes = 0; c.wtris = 0; c.walive = 0;
-    f3 o = F3(0.0f, 0.0f, 0.0f), d = F3(0.0f, 0.0f, 1.0f), inv = F3(0.0f, 0.0f, 1.0f);
-    float t = RT_INF, hu = 0.0f, hv = 0.0f;
-    uint32_t seq = 0xFFFFFFFFu, rec = 0xFFFFFFFFu, my = 0u;
-    int cur = RT_DONE, sp = 0;
-    bool busy = false;             // the lane holds a path whose hit record is not written yet
-    for (;;) {
-        // ---- service: ended rays leave their hit record, idle lanes take the next paths of the wave's chunk -----------
-        if (busy && cur == RT_DONE) {
-            hits[my] = make_float4(t, hu, hv, __uint_as_float(rec));
-            busy = false;
-        }
-        unsigned long long idle = __ballot(!busy);
-        while (idle && more) {
-            if (chunk_next >= chunk_end) {
-                uint32_t b = 0u;
-                if (lane == 0u) b = (uint32_t)atomicAdd(work, (unsigned long long)RT_TRACE_CHUNK);
-                b = (uint32_t)__builtin_amdgcn_readfirstlane((int)b);
-                if (b >= n) { more = false; break; }
-                chunk_next = b; chunk_end = b + RT_TRACE_CHUNK < n ? b + RT_TRACE_CHUNK : n;
-            }
-            const uint32_t i = chunk_next + (uint32_t)__builtin_popcountll(idle & below);
-            if (!busy && i < chunk_end) {
-                o = F3(qi.ox[i], qi.oy[i], qi.oz[i]);
-                d = F3(qi.dx[i], qi.dy[i], qi.dz[i]);
-                inv = ray_inv<WIDE>(d);
-                t = RT_INF; hu = 0.0f; hv = 0.0f; seq = 0xFFFFFFFFu; rec = 0xFFFFFFFFu;
-                cur = ray_has_nan(o, d) ? RT_DONE : 0; sp = 0;
-                my = i; busy = true;
-            }
-            const uint32_t took = (uint32_t)__builtin_popcountll(idle);
-            chunk_next = chunk_next + took < chunk_end ? chunk_next + took : chunk_end;
-            idle = __ballot(!busy);
-        }
-        if (__ballot(busy) == 0ull) break;                 // nothing in flight and nothing left to take
-        if (__ballot(cur != RT_DONE) == 0ull) continue;    // only rays that ended at once (NaN): write them, take more
-        // ---- hot loop: one voted step per trip (the loop of stream_body / traverse<>) -----------------------------------
-        uint32_t n_done, n_live;
-        do {
-            const unsigned long long m_node = __ballot(cur >= 0);
-            const uint32_t n_node = (uint32_t)__builtin_popcountll(m_node);
-            n_done = (uint32_t)__builtin_popcountll(__ballot(cur == RT_DONE));
-            const uint32_t n_leaf = 64u - n_done - n_node;
-            if (n_node * vote_tri >= n_leaf * vote_node) {
-                if (cur >= 0) {
-                    const float4 *p = reinterpret_cast<const float4 *>(nodes + cur);
-                    float4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3];
-                    if (COUNT) { c.nodes++; if (lane == (uint32_t)__builtin_ctzll(m_node)) { c.wnodes++; c.walive += n_node + n_leaf; } }
-                    if (WIDE) wide_decide(q0, q1, q2, q3, o, inv, t, cur, sp, stk, ovf);
-                    else node_decide(q0, q1, q2, q3, o, inv, t, cur, sp, stk, ovf);
-                }
-            } else {
-                if (cur < 0 && cur != RT_DONE) {
-                    if (cur == RT_CHILD_NONE) cur = stack_pop(sp, stk, ovf);
-                    else {
-                        uint32_t code = (uint32_t)(~cur);
-                        uint32_t first = code >> 3, left = code & 7u;
-                        const float4 *r = reinterpret_cast<const float4 *>(recs + first);
-                        float4 r0 = r[0], r1 = r[1], r2 = r[2];
-                        if (COUNT) { c.tris++; if (lane == (uint32_t)__builtin_ctzll(__ballot(true))) c.wtris++; }
-                        float dst, u, v;
-                        bool ok = prim_test(o, d, r0, r1, r2, dst, u, v);
-                        uint32_t sq = __float_as_uint(r2.w);
-                        ok = ok && (dst < t || (dst == t && sq < seq));
-                        if (ok && !(flags & RT_FLAG_NO_MESH_CULL) && __float_as_uint(r2.z) != RT_REC_SPHERE) {   // per-mesh AABB cull of wgsl:155
-                            const float4 *mp = reinterpret_cast<const float4 *>(meshes + __float_as_uint(r2.z));
-                            float4 m1 = mp[1], m2 = mp[2];
-                            ok = ray_aabb_ref(o, exact_inv<WIDE>(inv, d), F3(m1.x, m1.y, m1.z), F3(m2.x, m2.y, m2.z));
-                            if (COUNT) c.meshes++;
-                        }
-                        if (ok) { t = dst; seq = sq; rec = first; hu = u; hv = v; }
-                        if (left == 0u) cur = stack_pop(sp, stk, ovf);
-                        else cur = ~(int)(((first + 1u) << 3) | (left - 1u));
-                    }
-                }
-            }
-            n_done = (uint32_t)__builtin_popcountll(__ballot(cur == RT_DONE));
-            n_live = 64u - n_done;
-        } while (!(n_live == 0u || (more && n_done >= refill_min)));
-    }
-    if (COUNT) {
-        wave_sum(counters + RT_CNT_NODES, c.nodes);
-        wave_sum(counters + RT_CNT_TRIS, c.tris);
-        wave_sum(counters + RT_CNT_MESH, c.meshes);
-        wave_sum(counters + RT_CNT_WNODE, c.wnodes);
-        wave_sum(counters + RT_CNT_WTRI, c.wtris);
-        wave_sum(counters + RT_CNT_WALIVE, c.walive);
-    }
-}
-
-// the other half of a bounce segment: scatter (or add the sky and end), compact the survivors into the next queue
-__global__ __launch_bounds__(RT_BLOCK) void k_path_shade(RtSceneDev S, int is_last, float4 *__restrict__ contrib, uint32_t n_px, RtPathQueue qi,
-                                                         const float4 *__restrict__ hits, RtPathQueue qo,
-                                                         unsigned long long *__restrict__ counters, int qi_ctr, int qo_ctr) {
-    const uint32_t n = (uint32_t)counters[qi_ctr];
-    uint32_t n_bounce = 0;
-    for (uint32_t vb = blockIdx.x; vb * RT_BLOCK < n; vb += gridDim.x) {
-        const uint32_t i = vb * RT_BLOCK + threadIdx.x;
-        bool alive = false;
-        f3 o, d, col; uint32_t rng = 0, pixel = 0;
-        if (i < n) {
-            o = F3(qi.ox[i], qi.oy[i], qi.oz[i]);
-            d = F3(qi.dx[i], qi.dy[i], qi.dz[i]);
-            const float4 hr = hits[i];
-            Hit h;
-            h.t = hr.x; h.u = hr.y; h.v = hr.z; h.seq = 0u; h.tri = 0xFFFFFFFFu; h.mesh = 0u;
-            const uint32_t rec = __float_as_uint(hr.w);
-            h.hit = rec != 0xFFFFFFFFu;
-            if (h.hit) {
-                float4 r2 = reinterpret_cast<const float4 *>(S.recs + rec)[2];
-                h.tri = __float_as_uint(r2.y); h.mesh = __float_as_uint(r2.z);
-            }
-            col = F3(qi.cr[i], qi.cg[i], qi.cb[i]);
-            rng = qi.rng[i]; pixel = qi.pixel[i];                // pixel | sample slot << RT_PATH_SLOT_SHIFT
-            alive = path_scatter(S, h, o, d, col, rng, contrib + (size_t)(pixel >> RT_PATH_SLOT_SHIFT) * n_px + (pixel & RT_PATH_PIXEL_MASK)) && !is_last;
-            ++n_bounce;
-        }
-        uint32_t slot = queue_slot(counters + qo_ctr, alive);
-        if (alive) {
-            qo.ox[slot] = o.x; qo.oy[slot] = o.y; qo.oz[slot] = o.z;
-            qo.dx[slot] = d.x; qo.dy[slot] = d.y; qo.dz[slot] = d.z;
-            qo.cr[slot] = col.x; qo.cg[slot] = col.y; qo.cb[slot] = col.z;
-            qo.rng[slot] = rng; qo.pixel[slot] = pixel;
-        }
-    }
-    wave_sum(counters + RT_CNT_BOUNCE, n_bounce);
-}
+// (Round 2 measured three re-shapings of the bounce segments and kept none as the default; round 3 removed their code, which is
+// in the history at fa55bd4, measurements in profiles/r2 and DESIGN.md section 4.1: the queue regrouped by ray direction inside
+// the kernel (k_path_bounce_sorted: -2 ... -3 % wave trips, +2 ... +5 % time), and the segment split into a lane-refilled
+// traversal kernel + a scatter kernel (k_path_trace / k_path_shade: -38 % wave trips, +20 ... +30 % time).)
 
 // ---- f1 refit on the GPU: vertices moved, topology unchanged -----------------------------
 // One launch per tree level, deepest first (children are finished before their parent reads them; a kernel
@@ -1848,7 +1466,7 @@ hipError_t rtk_launch_primary(hipStream_t st, const RtSceneDev &S, const RtViewD
         // 1 M-triangle soup 0.412 -> 0.396; one frame at a time the same setting costs 10 %)
         if (per_cu == 0) per_cu = tree <= ((size_t)4 << 20) ? 3u : (tree <= ((size_t)16 << 20) || tune.frames_in_flight >= 3u ? 5u : 8u);
         // 8 waves per SIMD with frames in flight (k_stream8), else the 7-wave build; tune.stream_waves (7 / 8) overrides for A/Bs
-        const bool eight = tune.pool_dep == 0u && (tune.stream_waves ? tune.stream_waves == 8u : tune.frames_in_flight >= 3u);
+        const bool eight = tune.stream_waves ? tune.stream_waves == 8u : tune.frames_in_flight >= 3u;
         const uint32_t cu_holds = eight ? 8u : (uint32_t)RT_STREAM_WAVES;
         if (per_cu > cu_holds) per_cu = cu_holds;      // what a CU can hold: later blocks would only find empty queues
         uint32_t need = (sh.n_owned * sh.tile * sh.tile + RT_BLOCK - 1) / RT_BLOCK;
@@ -1858,27 +1476,14 @@ hipError_t rtk_launch_primary(hipStream_t st, const RtSceneDev &S, const RtViewD
         RtStreamTune tn;
         tn.refill_min = tune.refill_min; tn.finish_min = tune.finish_min; tn.uni_min = tune.uni_min;
         tn.vote_node = wide ? tune.wide_vote_node : tune.vote_node; tn.vote_tri = wide ? tune.wide_vote_tri : tune.vote_tri;
-        tn.pool_dep = tune.pool_dep; tn.pool_pick = tune.pool_pick; tn.pool_drain = tune.pool_drain;
-#define RT_LAUNCH_STREAM(C, W, P) \
-    hipLaunchKernelGGL((k_stream<C, W, P>), dim3(grid), dim3(RT_BLOCK), 0, st, S, V, sh, flags, tn, (float4 *)rgba, prim, t, counters)
-#define RT_LAUNCH_STREAM8(C, W) \
-    hipLaunchKernelGGL((k_stream8<C, W>), dim3(grid), dim3(RT_BLOCK), 0, st, S, V, sh, flags, tn, (float4 *)rgba, prim, t, counters)
+#define RT_LAUNCH_STREAM(K, C, W) \
+    hipLaunchKernelGGL((K<C, W>), dim3(grid), dim3(RT_BLOCK), 0, st, S, V, sh, flags, tn, (float4 *)rgba, prim, t, counters)
         if (eight) {
-            if (count) { if (wide) RT_LAUNCH_STREAM8(true, true); else RT_LAUNCH_STREAM8(true, false); }
-            else { if (wide) RT_LAUNCH_STREAM8(false, true); else RT_LAUNCH_STREAM8(false, false); }
-            return hipGetLastError();
-        }
-#undef RT_LAUNCH_STREAM8
-        const int variant = (count ? 4 : 0) | (wide ? 2 : 0) | (tn.pool_dep != 0u ? 1 : 0);
-        switch (variant) {
-            case 0: RT_LAUNCH_STREAM(false, false, false); break;
-            case 1: RT_LAUNCH_STREAM(false, false, true); break;
-            case 2: RT_LAUNCH_STREAM(false, true, false); break;
-            case 3: RT_LAUNCH_STREAM(false, true, true); break;
-            case 4: RT_LAUNCH_STREAM(true, false, false); break;
-            case 5: RT_LAUNCH_STREAM(true, false, true); break;
-            case 6: RT_LAUNCH_STREAM(true, true, false); break;
-            default: RT_LAUNCH_STREAM(true, true, true); break;
+            if (count) { if (wide) RT_LAUNCH_STREAM(k_stream8, true, true); else RT_LAUNCH_STREAM(k_stream8, true, false); }
+            else { if (wide) RT_LAUNCH_STREAM(k_stream8, false, true); else RT_LAUNCH_STREAM(k_stream8, false, false); }
+        } else {
+            if (count) { if (wide) RT_LAUNCH_STREAM(k_stream, true, true); else RT_LAUNCH_STREAM(k_stream, true, false); }
+            else { if (wide) RT_LAUNCH_STREAM(k_stream, false, true); else RT_LAUNCH_STREAM(k_stream, false, false); }
         }
 #undef RT_LAUNCH_STREAM
         return hipGetLastError();
@@ -1918,16 +1523,6 @@ hipError_t rtk_launch_path_bounce(hipStream_t st, const RtSceneDev &S, uint32_t 
     if (nb == 0) return hipSuccess;
     uint32_t persist = (flags & (RT_FLAG_STATIC_GRID | RT_FLAG_BRUTE_FORCE)) ? 0u : 1u;
     uint32_t grid = persist && tune.persist_blocks < nb ? tune.persist_blocks : nb;
-    if (tune.path_sort && persist) {        // opt-in: the queue regrouped by direction inside the kernel
-        const uint32_t m = tune.path_sort < RT_SORT_MAX_M ? tune.path_sort : RT_SORT_MAX_M;
-        const uint32_t nc = (capacity + RT_BLOCK * m - 1) / (RT_BLOCK * m);
-        const uint32_t g = tune.persist_blocks < nc ? tune.persist_blocks : nc;
-        if (flags & RT_FLAG_COUNTERS)
-            hipLaunchKernelGGL(k_path_bounce_sorted<true>, dim3(g), dim3(RT_BLOCK), 0, st, S, flags, is_last, (float4 *)contrib, n_px, qin, qout, counters, qin_counter, qout_counter, m, tune.path_sort_key);
-        else
-            hipLaunchKernelGGL(k_path_bounce_sorted<false>, dim3(g), dim3(RT_BLOCK), 0, st, S, flags, is_last, (float4 *)contrib, n_px, qin, qout, counters, qin_counter, qout_counter, m, tune.path_sort_key);
-        return hipGetLastError();
-    }
     if (flags & RT_FLAG_COUNTERS)
         hipLaunchKernelGGL(k_path_bounce<true>, dim3(grid), dim3(RT_BLOCK), 0, st, S, flags, is_last, (float4 *)contrib, n_px, qin, qout, counters, qin_counter, qout_counter, persist);
     else
@@ -1935,30 +1530,6 @@ hipError_t rtk_launch_path_bounce(hipStream_t st, const RtSceneDev &S, uint32_t 
     return hipGetLastError();
 }
 
-
-hipError_t rtk_launch_path_trace_shade(hipStream_t st, const RtSceneDev &S, uint32_t flags, uint32_t capacity, int is_last, float *contrib,
-                                       uint32_t n_px, RtPathQueue qin, float *hits, RtPathQueue qout, unsigned long long *counters,
-                                       int qin_counter, int qout_counter, const RtTune &tune) {
-    uint32_t nb = (capacity + RT_BLOCK - 1) / RT_BLOCK;
-    if (nb == 0) return hipSuccess;
-    const bool wide = S.n_wide != 0u && !(flags & RT_FLAG_BINARY_TREE);
-    const RtBvhNode *nodes = wide ? reinterpret_cast<const RtBvhNode *>(S.wide) : S.nodes;
-    const uint32_t n_nodes = wide ? S.n_wide : S.n_nodes;
-    const uint32_t vn = wide ? tune.wide_vote_node : tune.vote_node, vt = wide ? tune.wide_vote_tri : tune.vote_tri;
-    uint32_t grid = tune.persist_blocks < nb ? tune.persist_blocks : nb;
-    hipError_t e = hipMemsetAsync(counters + RT_CNT_WORK, 0, sizeof(unsigned long long), st);
-    if (e != hipSuccess) return e;
-    const bool count = (flags & RT_FLAG_COUNTERS) != 0;
-#define RT_LAUNCH_TRACE(C, W) \
-    hipLaunchKernelGGL((k_path_trace<C, W>), dim3(grid), dim3(RT_BLOCK), 0, st, nodes, S.recs, S.meshes, n_nodes, flags, qin, (float4 *)hits, counters, qin_counter, tune.path_refill_min, vn, vt)
-    if (count) { if (wide) RT_LAUNCH_TRACE(true, true); else RT_LAUNCH_TRACE(true, false); }
-    else { if (wide) RT_LAUNCH_TRACE(false, true); else RT_LAUNCH_TRACE(false, false); }
-#undef RT_LAUNCH_TRACE
-    if ((e = hipGetLastError()) != hipSuccess) return e;
-    uint32_t sgrid = nb < tune.cus * 8u ? nb : tune.cus * 8u;
-    hipLaunchKernelGGL(k_path_shade, dim3(sgrid), dim3(RT_BLOCK), 0, st, S, is_last, (float4 *)contrib, n_px, qin, (const float4 *)hits, qout, counters, qin_counter, qout_counter);
-    return hipGetLastError();
-}
 
 static uint32_t stream_grid(size_t n) {
     size_t b = (n + 255) / 256;

@@ -394,49 +394,6 @@ def test_present_async_delivers_the_bytes_of_each_frame_in_flight(n):
         assert len({t for t, _, _ in open_tickets}) == n
 
 
-@pytest.mark.parametrize("env", [{"RT_TUNE_POOL_DEP": "16"},{"RT_TUNE_POOL_DEP": "24", "RT_TUNE_POOL_PICK": "8", "RT_TUNE_POOL_DRAIN": "1"},
-                                 {"RT_TUNE_PATH_SPLIT": "1", "RT_TUNE_PATH_REFILL_MIN": "16"}, {"RT_TUNE_PATH_SPLIT": "1", "RT_TUNE_PATH_REFILL_MIN": "1"},
-                                 {"RT_TUNE_PATH_SORT": "1"}, {"RT_TUNE_PATH_SORT": "6", "RT_TUNE_PATH_SORT_KEY": "1"}])
-def test_measured_opt_in_variants_stay_bit_identical(env, monkeypatch):
-    """Round 2 measured three re-packing schemes and kept none as the default: the block tail pool of
-    k_stream (RT_TUNE_POOL_DEP), bounce segments split into a lane-refilled traversal kernel + a scatter kernel
-    (RT_TUNE_PATH_SPLIT), and the bounce queue regrouped by ray direction inside the bounce kernel (RT_TUNE_PATH_SORT).
-    They stay in the library for A/B runs, so they stay correct: same frames, same counted visits."""
-    for k, v in env.items():
-        monkeypatch.setenv(k, v)
-    app = soup_app(300, 0x5EED0003, 640, 360)
-    app.camera_frame_scene(1.0)
-    scene = app.prepare_meshinfo()
-    osc, view = oracle_scene(scene), oracle_view(app)
-    with rt.Context(0) as ctx:                         # the RT_TUNE_* variables are read by rt_create
-        ctx.upload_scene(scene)
-        m, p = app.camera_view()
-        ctx.set_view(m, p, 640, 360)
-        tree = orc.Tree(*ctx.read_bvh(), ctx.read_bvh_wide())
-        for extra in (0, rt.FLAG_BINARY_TREE):
-            t_ = orc.Tree(*ctx.read_bvh(), None) if extra else tree
-            assert ctx.render(flags=rt.FLAG_SHADOW | rt.FLAG_COUNTERS | extra) == rt.RT_OK
-            c = ctx.counters()
-            rgba_w, prim_w, t_w, rays_w, cnt_w = orc.render_primary_tree(osc, t_, view, orc.FLAG_SHADOW, threads=16)
-            assert bitwise_equal(ctx.read_prim_ids(), prim_w) and bitwise_equal(ctx.read_radiance(), rgba_w) and bitwise_equal(ctx.read_hit_t(), t_w)
-            assert (c.node_visits, c.tri_tests, c.mesh_aabb_tests) == cnt_w and c.rays_primary + c.rays_shadow == rays_w
-            assert ctx.render(flags=rt.FLAG_PATH_TRACE | rt.FLAG_COUNTERS | extra, spp=5, max_segments=6, seed=3) == rt.RT_OK
-            c = ctx.counters()
-            acc_w, segs_w, cnt_p = orc.render_path_tree(osc, t_, view, spp=5, max_segments=6, seed=3, threads=16)
-            assert bitwise_equal(ctx.read_accumulation(), acc_w)
-            assert c.rays_primary + c.rays_bounce == segs_w and (c.node_visits, c.tri_tests, c.mesh_aabb_tests) == cnt_p
-        # ragged frame, a shard, the default scene's tiny tree (every wave deposits at the frame's end)
-        app2 = default_app(333, 190)
-        sc2 = app2.prepare_meshinfo()
-        ctx.upload_scene(sc2)
-        m2, p2 = app2.camera_view()
-        ctx.set_view(m2, p2, 333, 190)
-        rgba_o, prim_o, _, _ = orc.render_primary(oracle_scene(sc2), oracle_view(app2), orc.FLAG_SHADOW, threads=16)
-        for _ in range(3):
-            assert ctx.render(flags=rt.FLAG_SHADOW) == rt.RT_OK
-            assert bitwise_equal(ctx.read_prim_ids(), prim_o) and bitwise_equal(ctx.read_radiance(), rgba_o)
-
-
 def test_config4_sample_slices_sum_to_the_unsliced_frame():
     """configs[4] (sample slicing): the 10 M-triangle scene, <= 8 segments, 8 samples per pixel rendered as EIGHT
     slices of one sample each (sample_first = r, one RNG stream: what rank r of 8 renders), their running sums added in rank

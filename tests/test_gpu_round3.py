@@ -86,11 +86,9 @@ def test_stream_kernel_builds_one_frame_at_a_time_against_the_oracle_walk(waves,
             assert bitwise_equal(ctx.read_prim_ids(), prim_w) and bitwise_equal(ctx.read_radiance(), rgba_w)
 
 
-@pytest.mark.parametrize("split", ["0", "1"])
-def test_path_tracing_an_empty_scene_is_all_sky(split, monkeypatch):
-    """with no tree to walk the split bounce kernels (RT_TUNE_PATH_SPLIT=1) handed out no path and left the
-    hit records unwritten; the frame must be what the fused kernel and the oracle give: every path ends in the sky."""
-    monkeypatch.setenv("RT_TUNE_PATH_SPLIT", split)
+def test_path_tracing_an_empty_scene_is_all_sky():
+    """With no tree to walk every path ends in the sky at once: the frame must be what the oracle gives.  (ADVICE r2 found the
+    round-2 split bounce kernels leaving their hit records unwritten here; those kernels are gone, the case stays.)"""
     app = default_app(160, 90)
     scene = app.prepare_meshinfo()
     empty = rt.Scene(scene.triangles[:0], scene.meshes[:0], scene.vertices[:0], scene.materials[:0])
@@ -103,3 +101,61 @@ def test_path_tracing_an_empty_scene_is_all_sky(split, monkeypatch):
         acc_o, _ = orc.render_path(oracle_scene(empty), orc.make_view(m, p, 160, 90), 2, 4, seed=3, threads=4)
         assert bitwise_equal(acc, acc_o)
         assert np.allclose(acc[..., :3], 2 * np.array([0.5, 0.71, 0.86], np.float32)) and np.all(acc[..., 3] == 2)
+
+
+@pytest.mark.parametrize("env", [{"RT_TUNE_REFILL_MIN": "32", "RT_TUNE_FINISH_MIN": "32"}, {"RT_TUNE_FINISH_MIN": "8"},
+                                 {"RT_TUNE_UNI_MIN": "65"}, {"RT_TUNE_UNI_MIN": "1", "RT_TUNE_WIDE_VOTE_NODE": "1", "RT_TUNE_WIDE_VOTE_TRI": "3"},
+                                 {"RT_TUNE_BLOCKS_PER_CU": "2", "RT_TUNE_SAMPLE_BATCH": "4"}])
+def test_scheduling_knobs_never_change_results_or_counted_visits(env, monkeypatch):
+    """Work distribution, hand-over thresholds, vote weights, the scalar node fetch and the sample batch are SCHEDULING: a ray's
+    own sequence of steps does not depend on them, so frames and counted visits must equal the oracle's walk under any setting
+    (mixed primary / shadow waves included: partial refills and early hand-over).  One voted-trip source serves all of them
+    since round 3 (RT_VOTED_TRIP); this is its regression test on both trees, primary + shadow and path tracing."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    app = soup_app(300, 0x5EED0003, 640, 360)
+    app.camera_frame_scene(1.0)
+    scene = app.prepare_meshinfo()
+    osc, view = oracle_scene(scene), oracle_view(app)
+    with rt.Context(0) as ctx:                         # the RT_TUNE_* variables are read by rt_create
+        ctx.upload_scene(scene)
+        m, p = app.camera_view()
+        ctx.set_view(m, p, 640, 360)
+        tree = orc.Tree(*ctx.read_bvh(), ctx.read_bvh_wide())
+        for extra in (0, rt.FLAG_BINARY_TREE, rt.FLAG_STATIC_GRID):
+            t_ = orc.Tree(*ctx.read_bvh(), None) if extra & rt.FLAG_BINARY_TREE else tree
+            assert ctx.render(flags=rt.FLAG_SHADOW | rt.FLAG_COUNTERS | extra) == rt.RT_OK
+            c = ctx.counters()
+            rgba_w, prim_w, t_w, rays_w, cnt_w = orc.render_primary_tree(osc, t_, view, orc.FLAG_SHADOW, threads=16)
+            assert bitwise_equal(ctx.read_prim_ids(), prim_w) and bitwise_equal(ctx.read_radiance(), rgba_w) and bitwise_equal(ctx.read_hit_t(), t_w)
+            assert (c.node_visits, c.tri_tests, c.mesh_aabb_tests) == cnt_w and c.rays_primary + c.rays_shadow == rays_w
+            assert ctx.render(flags=rt.FLAG_PATH_TRACE | rt.FLAG_COUNTERS | extra, spp=5, max_segments=6, seed=3) == rt.RT_OK
+            c = ctx.counters()
+            acc_w, segs_w, cnt_p = orc.render_path_tree(osc, t_, view, spp=5, max_segments=6, seed=3, threads=16)
+            assert bitwise_equal(ctx.read_accumulation(), acc_w)
+            assert c.rays_primary + c.rays_bounce == segs_w and (c.node_visits, c.tri_tests, c.mesh_aabb_tests) == cnt_p
+        # ragged frame, the default scene's tiny tree
+        app2 = default_app(333, 190)
+        sc2 = app2.prepare_meshinfo()
+        ctx.upload_scene(sc2)
+        m2, p2 = app2.camera_view()
+        ctx.set_view(m2, p2, 333, 190)
+        rgba_o, prim_o, _, _ = orc.render_primary(oracle_scene(sc2), oracle_view(app2), orc.FLAG_SHADOW, threads=16)
+        for _ in range(3):
+            assert ctx.render(flags=rt.FLAG_SHADOW) == rt.RT_OK
+            assert bitwise_equal(ctx.read_prim_ids(), prim_o) and bitwise_equal(ctx.read_radiance(), rgba_o)
+
+
+def test_measure_gather_rates_orders_the_memory_hierarchy():
+    """rt_measure_gather_rates (measurement aid behind bench.py's roofline.gather): ten positive rates, caches faster than the
+    Infinity Cache faster than a 4 GiB spread of HBM, and bad arguments refused."""
+    import ctypes as C
+    r = rt.measure_gather_rates(0)
+    assert list(r) == list(rt.GATHER_LEVELS)
+    assert all(v["independent"] > 1.0 and v["dependent"] > 1.0 for v in r.values())
+    assert r["l1_16KiB"]["independent"] > r["infinity_cache_128MiB"]["independent"] > r["hbm_4GiB"]["independent"]
+    assert r["l2_2MiB"]["independent"] > 2.0 * r["hbm_1GiB"]["independent"]
+    vals = (C.c_double * 10)()
+    assert rt.lib().rt_measure_gather_rates(0, vals, 9) == rt.RT_ERR_ARG
+    assert rt.lib().rt_measure_gather_rates(99, vals, 10) == rt.RT_ERR_ARG
+    assert rt.lib().rt_measure_gather_rates(0, None, 10) == rt.RT_ERR_ARG

@@ -5,7 +5,7 @@ sys.path[:0] = [os.path.dirname(os.path.dirname(os.path.abspath(__file__)))]
 import ray_tracing_amd as rt
 SETTINGS = [{}, {"RT_TUNE_BLOCKS_PER_CU": "7"}, {"RT_TUNE_BLOCKS_PER_CU": "6"}, {"RT_TUNE_BLOCKS_PER_CU": "5"}, {"RT_TUNE_BLOCKS_PER_CU": "4"},
             {"RT_TUNE_REFILL_MIN": "48"}, {"RT_TUNE_REFILL_MIN": "32"}, {"RT_TUNE_FINISH_MIN": "48"}, {"RT_TUNE_FINISH_MIN": "32"},
-            {"RT_TUNE_REFILL_MIN": "32", "RT_TUNE_FINISH_MIN": "32"}, {"RT_TUNE_POOL_DEP": "16"}, {"RT_TUNE_WIDE_VOTE_NODE": "2"}, {"RT_TUNE_WIDE_VOTE_NODE": "4"},
+            {"RT_TUNE_REFILL_MIN": "32", "RT_TUNE_FINISH_MIN": "32"}, {"RT_TUNE_WIDE_VOTE_NODE": "2"}, {"RT_TUNE_WIDE_VOTE_NODE": "4"},
             {"RT_TUNE_UNI_MIN": "65"}, {"RT_TUNE_UNI_MIN": "8"}]
 KEYS = sorted({k for s in SETTINGS for k in s})
 scenes = []

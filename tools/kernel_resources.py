@@ -21,22 +21,35 @@ DEFAULT_SO = os.path.join(ROOT, "ray-tracing_amd", "librt_amd.so")
 MAGIC = b"__CLANG_OFFLOAD_BUNDLE__"
 
 
-def device_elf(so_path=DEFAULT_SO, arch="gfx950"):
-    """The device ELF for `arch` out of the (uncompressed) clang offload bundle in the library's .hip_fatbin."""
+def device_elfs(so_path=DEFAULT_SO, arch="gfx950"):
+    """Every device ELF for `arch` in the library's .hip_fatbin: one (uncompressed) clang offload bundle per .hip translation
+    unit (csrc/rt_kernels.hip, csrc/rt_tools.hip)."""
     blob = open(so_path, "rb").read()
+    out = []
     base = blob.find(MAGIC)
-    if base < 0:
-        raise RuntimeError(f"{so_path}: no clang offload bundle (compressed bundles are not handled)")
-    (n,) = struct.unpack_from("<Q", blob, base + len(MAGIC))
-    off = base + len(MAGIC) + 8
-    for _ in range(n):
-        o, size, tlen = struct.unpack_from("<QQQ", blob, off)
-        off += 24
-        triple = blob[off:off + tlen].decode()
-        off += tlen
-        if arch in triple and size:
-            return blob[base + o: base + o + size]
-    raise RuntimeError(f"{so_path}: no {arch} code object in the bundle")
+    while base >= 0:
+        (n,) = struct.unpack_from("<Q", blob, base + len(MAGIC))
+        off = base + len(MAGIC) + 8
+        for _ in range(n):
+            o, size, tlen = struct.unpack_from("<QQQ", blob, off)
+            off += 24
+            triple = blob[off:off + tlen].decode()
+            off += tlen
+            if arch in triple and size:
+                out.append(blob[base + o: base + o + size])
+        base = blob.find(MAGIC, base + len(MAGIC))
+    if not out:
+        raise RuntimeError(f"{so_path}: no {arch} code object in an uncompressed clang offload bundle")
+    return out
+
+
+def device_elf(so_path=DEFAULT_SO, arch="gfx950"):
+    """The device ELF that holds the render kernels (the one with k_stream in its symbol table)."""
+    elfs = device_elfs(so_path, arch)
+    for e in elfs:
+        if b"k_stream" in e:
+            return e
+    return elfs[0]
 
 
 def _notes(elf):

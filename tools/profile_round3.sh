@@ -1,6 +1,6 @@
 #!/bin/bash
 # One profiling round on the GPU box (round 3): rocprofv3 kernel stats of the default bench command (and of the same command one
-# frame at a time), PMC passes for the kernel that runs alone (k_stream<false, true, false>), for the kernel of the TIMED region
+# frame at a time), PMC passes for the kernel that runs alone (k_stream<false, true>), for the kernel of the TIMED region
 # (k_stream8<false, true>, forced with RT_TUNE_STREAM_WAVES=8 because a counter pass serialises launches) and for the path
 # kernels of configs[2] and of the 10 M-triangle scene; profiles/pmc_traffic.json regenerated from them; the bench line.
 # Output under gpurun_out/prof_r3 (copy what is to be judged into profiles/r3/).
@@ -21,7 +21,7 @@ echo stats ok
 if [ "${1:-}" = "stats-only" ]; then exit 0; fi
 fi
 if [ "$STAGE" = "all" ] || [ "$STAGE" = "a" ]; then
-bash tools/pmc_full.sh r3_field "k_stream<false, true, false>" --in-flight 1 > $P/pmc_field.log 2>&1 || { tail $P/pmc_field.log; exit 1; }
+bash tools/pmc_full.sh r3_field "k_stream<false, true>" --in-flight 1 > $P/pmc_field.log 2>&1 || { tail $P/pmc_field.log; exit 1; }
 RT_TUNE_STREAM_WAVES=8 bash tools/pmc_full.sh r3_field8 "k_stream8<false, true>" --in-flight 1 > $P/pmc_field8.log 2>&1 || { tail $P/pmc_field8.log; exit 1; }
 fi
 if [ "$STAGE" = "all" ] || [ "$STAGE" = "b" ]; then

@@ -255,7 +255,18 @@ def side_workload(rt, orc, name, local_rank, steps, in_flight, pmc_section=None,
             out["gather"] = g
         if pmc_section is not None:
             out["counters"] = pmc_section
+            ks = pmc_section.get("k_path_start<false>") if isinstance(pmc_section, dict) else None
             kb = pmc_section.get("k_path_bounce<false>") if isinstance(pmc_section, dict) else None
+            if ks and rates and spp:
+                # the whole frame's traffic beyond the L2 -- one k_path_start per batch of samples, segs - 1 bounce launches (the
+                # committed passes give bytes per launch, averaged over a frame's launches) -- over the frame time as timed here
+                n_start = 1 if spp in (1, 4, 16) else spp
+                fb = ks["hbm_bytes_per_launch"] * n_start + (kb["hbm_bytes_per_launch"] * (segs - 1) * n_start if kb else 0)
+                r = fb / 64.0 / (ms_n * 1e-3) / 1e9
+                out["frame_beyond_l2"] = {"bytes_per_frame": int(fb), "Ggather_s": round(r, 1), "TBps": round(r * 64 / 1e3, 2),
+                                          "ceiling_Ggather_s": round(rates["hbm_1GiB"]["independent"], 1), "frac": round(r / rates["hbm_1GiB"]["independent"], 4),
+                                          "is": "HBM + Infinity Cache bytes of a frame's launches (committed counter passes) / 64 B over the frame time measured in THIS run with frames in flight, "
+                                                "against this GPU's rate of random 64-B gathers from 1 GiB (rt_measure_gather_rates)"}
             if kb and rates and kb.get("avg_duration_us_under_pmc"):
                 r = kb["hbm_bytes_per_launch"] / 64.0 / (kb["avg_duration_us_under_pmc"] * 1e-6) / 1e9
                 out["bounce_launch_beyond_l2"] = {"Ggather_s": round(r, 1), "TBps": round(r * 64 / 1e3, 2),

@@ -128,7 +128,8 @@ def test_bench_self_launch_starts_ranks_and_fails_loudly_without_gpus():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
                        env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode != 0
-    assert r.stderr.count("needs a GPU") == 2 and "{" not in r.stdout
+    # the first rank to refuse takes the other down with it (multi_gpu.launch_ranks): one or both messages, never a bench line
+    assert 1 <= r.stderr.count("needs a GPU") <= 2 and "{" not in r.stdout
 
 
 def test_launch_ranks_ends_the_run_at_once_when_one_rank_dies(tmp_path):

@@ -3,10 +3,11 @@
 
 Workload at N=1 (BASELINE.json configs[1]): synthetic 10k-sphere field,
 reference-faithful tessellation (ico(5): 7.2 M triangles + ground plane), 1920x1080, one primary
-ray per pixel + one shadow ray per hit.  A step = one frame through rt_render (C ABI).
-The camera MOVES: step k renders view k % 8 of an orbit around the scene (45 degrees apart, same distance and height;
-view 0 is the camera of rounds 1 and 2), so the frames in flight are different frames -- four copies of one frame would
-share their whole working set in the caches.  The same-view figure is printed beside it (`same_view`).
+ray per pixel + one shadow ray per hit.  The camera MOVES: frame k renders view k % 8 of an orbit around the scene (45
+degrees apart, same distance and height; view 0 is the camera of rounds 1 and 2), so the frames in flight are different
+frames -- four copies of one frame would share their whole working set in the caches.  A STEP = one pass of the hot path over
+that batch of input: the orbit's 8 views, i.e. 8 frames through rt_render (C ABI); `ms_per_frame` is printed beside
+`ms_per_step`.  The same-view figure is printed too (`same_view`).
 N>1: scene replicated, one process per GPU (launched by torch.distributed.run, or -- when WORLD_SIZE is not set --
 by this script itself, which starts N rank processes before anything touches a GPU).  --mode tiles (the default,
 BASELINE.json north_star / SURVEY 8e): ONE frame sharded by 64x64 screen tiles round-robin over the ranks, every rank
@@ -240,10 +241,10 @@ def side_workload(rt, orc, name, local_rank, steps, in_flight, pmc_section=None,
             return (time.perf_counter() - t0) / steps * 1e3
         ms_n = run(in_flight)
         ms_1 = run(1)
-        out = {"workload": name, "value": round(rays / ms_n / 1e3, 2), "unit": "Mrays/s", "ms_per_step": round(ms_n, 4), "steps": steps,
+        out = {"workload": name, "value": round(rays / ms_n / 1e3, 2), "unit": "Mrays/s", "ms_per_frame": round(ms_n, 4), "frames": steps,
                "frames_in_flight": (min(in_flight, 2) if spp else in_flight), "rays_per_step": int(rays), "triangles": int(info.n_triangles),
                "resolution": f"{W}x{H}", "rays": (f"path tracing, {spp} spp, <= {segs} segments" if spp else "primary+shadow, 1 spp"),
-               "one_frame_at_a_time": {"value": round(rays / ms_1 / 1e3, 2), "ms_per_step": round(ms_1, 4)},
+               "one_frame_at_a_time": {"value": round(rays / ms_1 / 1e3, 2), "ms_per_frame": round(ms_1, 4)},
                "bytes_per_ray": round(alg / max(rays, 1), 1),
                "frac": round(alg / (ms_1 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                "frac_is": "SURVEY 8d's algorithmic bytes per frame / frame time one at a time / 8 TB/s (the caches serve most of those bytes)",
@@ -296,8 +297,8 @@ def side_workload(rt, orc, name, local_rank, steps, in_flight, pmc_section=None,
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)      # 0.12 s of frames: the four-deep pipeline's fill and drain (inside the timed region) weigh 1 %, not 4
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=25)       # a step = one pass over the orbit's views (8 frames): 200 frames, 0.12 s -- the four-deep pipeline's fill and drain (inside the timed region) weigh 1 %
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="sphere_field_10k_1080p_primary_shadow", choices=sorted(WORKLOADS))
     ap.add_argument("--mode", default="tiles", choices=["frames", "tiles", "samples"], help="N > 1 only; tiles = north_star's partitioning")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -438,7 +439,8 @@ def main():
         # direct reduce-scatter over the point-to-point links + gather of the resolved slices to rank 0
         reducer = multi_gpu.SampleReduce(H * W * 4, world, rank, "cpu" if gloo_s else f"cuda:{local_rank}", gather_to=0)
 
-    step_no = [0]          # steps since the start: step k renders view k % n_views on every rank
+    fps = n_views          # frames per step: one step = one pass over the orbit (BASELINE's "one pass over one batch of synthetic input": the batch is the orbit's views)
+    step_no = [0]          # frames since the start: frame k renders view k % n_views on every rank
     host_combined = [None]  # gloo rehearsal only: rank 0's combined frame of the last step (a host array)
 
     def step(f, fixed_view=None):
@@ -472,21 +474,21 @@ def main():
         """steps frames with n_frames in flight, bracketed by barrier + synchronize; returns (seconds, max over ranks; kernel ms
         per launch; rays traced by this rank; algorithmic bytes of this rank's launches; view of the last frame)."""
         configure(n_frames)
-        for _ in range(warmup):
+        for _ in range(warmup * fps):
             step(flags, fixed_view)
         quiesce()
         ctx.counters()                             # start the HIP-event sums afresh
         rays = alg = 0
         last = 0
         t0 = time.perf_counter()
-        for _ in range(steps):
+        for _ in range(steps * fps):
             last = step(flags | rt.FLAG_TIME_KERNELS, fixed_view)
             rays += rays_v[last]
             alg += alg_v[last]
         quiesce()
         dt_ = time.perf_counter() - t0
         kc = ctx.counters()                        # sums the per-launch HIP event pairs
-        k_ms = kc.kernel_ms / (steps if spp else max(kc.kernel_launches, 1))   # per launch; per frame when path tracing
+        k_ms = kc.kernel_ms / (steps * fps if spp else max(kc.kernel_launches, 1))   # per launch; per frame when path tracing
         if distributed:
             tt = torch.tensor([dt_], dtype=torch.float64, device="cuda")
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -569,10 +571,13 @@ def main():
             rates = None
     if rank == 0:
         import oracle_py as orc
+        n_frames_timed = args.steps * fps
         ms_per_step = dt / args.steps * 1e3
+        ms_per_frame = ms_per_step / fps
         value = total_rays / dt / 1e6
-        rays_step = rays_timed / args.steps                 # mean over the views the timed region rendered (this rank)
-        alg_bytes = alg_timed / args.steps
+        rays_step = rays_timed / args.steps                 # per step = per pass over the orbit (this rank)
+        rays_frame = rays_timed / n_frames_timed
+        alg_bytes = alg_timed / n_frames_timed              # per frame (= per launch of the primary / shadow kernel)
         cnt = cnts[last_view]
         hits_all = sum(c.rays_shadow for c in cnts)
         prim_all_v = sum(c.rays_primary for c in cnts)
@@ -582,7 +587,7 @@ def main():
         kernel_ms_in_flight = kernel_ms
         if one_at_a_time:
             kernel_ms = one_at_a_time[1]
-            alg_one = one_at_a_time[3] / args.steps
+            alg_one = one_at_a_time[3] / n_frames_timed
         else:
             alg_one = alg_bytes
         achieved = alg_one / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
@@ -633,31 +638,31 @@ def main():
                 # ... and the regime `value` is measured in: the kernel of the timed region (k_stream8 with >= 3 frames in
                 # flight), its instruction and byte counts per launch from passes of THAT kernel (forced with
                 # RT_TUNE_STREAM_WAVES=8 --in-flight 1: a counter pass serialises launches), over the time a frame takes in
-                # the timed region.  No launch is alone there, so time per frame -- ms_per_step -- is the denominator.
+                # the timed region.  No launch is alone there, so time per frame -- ms_per_step / frames_per_step -- is the denominator.
                 tf = tj.get("in_flight")
                 if overlapped and tf and tf.get("kernel") == kernel_timed:
                     peak_rate = tj.get("valu_peak_wave_insts_per_s_per_simd", 0.909e9)
-                    busy = tf["valu_insts_per_launch"] / N_SIMDS / (ms_per_step * 1e-3) / peak_rate
-                    hbm_if = tf["hbm_bytes_per_launch"] / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS
+                    busy = tf["valu_insts_per_launch"] / N_SIMDS / (ms_per_frame * 1e-3) / peak_rate
+                    hbm_if = tf["hbm_bytes_per_launch"] / (ms_per_frame * 1e-3) / 1e9 / HBM_PEAK_GBS
                     util = {"valu": round(busy, 4), "hbm": round(hbm_if, 4)}
                     lg_ = sum(lane_gathers_of(c_) for c_ in cnts) / n_views
                     # the vector-memory front end by the hardware's own counter: TA_BUSY of the serialised pass, carried over to
                     # the timed frame time (the same fetches in less time)
                     if tf.get("ta_busy") and tf.get("avg_duration_us_under_pmc"):
-                        util["vmem_front_end"] = round(tf["ta_busy"] * tf["avg_duration_us_under_pmc"] * 1e-3 / ms_per_step, 4)
+                        util["vmem_front_end"] = round(tf["ta_busy"] * tf["avg_duration_us_under_pmc"] * 1e-3 / ms_per_frame, 4)
                     if rates:
-                        util["gathers_vs_divergent_ceiling"] = round(lg_ / (ms_per_step * 1e-3) / 1e9 / rates["l2_2MiB"]["independent"], 4)
-                        util["beyond_l2_gathers"] = round(tf["hbm_bytes_per_launch"] / 64.0 / (ms_per_step * 1e-3) / 1e9 / rates["hbm_1GiB"]["independent"], 4)
+                        util["gathers_vs_divergent_ceiling"] = round(lg_ / (ms_per_frame * 1e-3) / 1e9 / rates["l2_2MiB"]["independent"], 4)
+                        util["beyond_l2_gathers"] = round(tf["hbm_bytes_per_launch"] / 64.0 / (ms_per_frame * 1e-3) / 1e9 / rates["hbm_1GiB"]["independent"], 4)
                     top = max((k_ for k_ in util if k_ != "gathers_vs_divergent_ceiling"), key=util.get)
                     in_flight_block = {
-                        "kernel": kernel_timed, "frames_in_flight": n_in_flight, "ms_per_frame": round(ms_per_step, 4),
+                        "kernel": kernel_timed, "frames_in_flight": n_in_flight, "ms_per_frame": round(ms_per_frame, 4),
                         "valu": {"busy": round(busy, 4), "lanes_active": tf["valu_lanes_active"], "frac": round(busy * tf["valu_lanes_active"], 4),
                                  "insts_per_launch": tf["valu_insts_per_launch"],
-                                 "busy_is": "VALU wave-instructions per launch / (1,024 SIMDs x calibrated issue rate x ms_per_step)"},
+                                 "busy_is": "VALU wave-instructions per launch / (1,024 SIMDs x calibrated issue rate x ms_per_frame)"},
                         "hbm_frac": round(hbm_if, 4), "traffic": tf["hbm_bytes_per_launch"], "l2_hit_rate": tf.get("l2_hit_rate"),
                         "ta_busy_alone": tf.get("ta_busy"),
                         "utilisation": util,
-                        "utilisation_is": "valu: issue rate against the calibrated peak; vmem_front_end: TA_BUSY of the serialised counter pass x its launch duration / ms_per_step; "
+                        "utilisation_is": "valu: issue rate against the calibrated peak; vmem_front_end: TA_BUSY of the serialised counter pass x its launch duration / ms_per_frame; "
                                           "gathers_vs_divergent_ceiling: counted lane-level 64-B gathers per second against rt_measure_gather_rates' cache-resident ceiling, which "
                                           "is for waves whose 64 lanes all fetch different lines -- lanes that share a node cost the front end one line (profiles/r3/gather_front_end_variants.txt), "
                                           "so this OVERSTATES its load; beyond_l2_gathers: HBM + Infinity Cache bytes / 64 B against random gathers from 1 GiB; hbm: the same bytes against the 8 TB/s streaming peak",
@@ -674,20 +679,21 @@ def main():
         else:
             bound_alone = "hbm (nominal; no current counters)"
         bound = in_flight_block["bound"] if in_flight_block else bound_alone
-        frac_timed = alg_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS
+        frac_timed = alg_bytes / (ms_per_frame * 1e-3) / 1e9 / HBM_PEAK_GBS
         g_main = None
         if not spp:
             tf_ = (tj or {}).get("in_flight") if (tj is not None and pmc.get("quoted")) else None
-            g_main = gather_block(rates, sum(lane_gathers_of(c_) for c_ in cnts) / n_views, ms_per_step, kernel_ms if overlapped else None,
+            g_main = gather_block(rates, sum(lane_gathers_of(c_) for c_ in cnts) / n_views, ms_per_frame, kernel_ms if overlapped else None,
                                   tf_["hbm_bytes_per_launch"] if (overlapped and tf_ and tf_.get("kernel") == kernel_timed) else traffic)
         out = {
             "metric": "Mrays/s", "value": round(value, 2), "unit": "Mrays/s", "n_gpus": world,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "ms_per_frame": round(ms_per_frame, 4),
             "higher_is_better": True, "scaling": "strong" if args.mode == "tiles" else "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": args.workload, "resolution": f"{W}x{H}", "rays": (f"path tracing, {spp} spp, <= {segs} segments" if spp else "primary+shadow, 1 spp"),
                        "triangles": int(info.n_triangles), "bvh_nodes": int(info.n_nodes),
-                       "views": n_views, "views_are": (f"step k renders view k % {n_views} of an orbit around the scene ({360 // n_views} degrees apart); view 0 = the camera of rounds 1-2" if n_views > 1 else "one camera"),
+                       "frames_per_step": fps, "step_is": (f"one pass over the orbit's {fps} views = {fps} frames through rt_render; {args.steps} steps = {n_frames_timed} frames timed" if fps > 1 else "one frame through rt_render"),
+                       "views": n_views, "views_are": (f"frame k renders view k % {n_views} of an orbit around the scene ({360 // n_views} degrees apart); view 0 = the camera of rounds 1-2" if n_views > 1 else "one camera"),
                        "rays_per_step_rank0": int(round(rays_step)), "rays_per_view_rank0": [int(r) for r in rays_v],
                        "primary_hit_fraction": round(hits_all / max(prim_all_v, 1), 4), "camera_radii": CAMERA_RADII, "frames_in_flight": n_in_flight,
                        "backend": (dist.get_backend() if distributed else None), "rccl_ranks": (dist.get_world_size() if distributed and dist.get_backend() == "nccl" else None),
@@ -699,7 +705,7 @@ def main():
                          "achieved_is": "ALGORITHMIC bytes per launch / kernel time one frame at a time (SURVEY 8d); the caches serve most of those bytes, so this is not a bound: "
                                         "see frac_at_timed_rate and in_flight",
                          "frac_at_timed_rate": round(frac_timed, 5), "frac_exceeds_1_at_timed_rate": bool(frac_timed > 1.0),
-                         "frac_at_timed_rate_is": "the same algorithmic bytes over ms_per_step (the regime `value` is measured in): above 1 proves that algorithmic bytes / HBM peak does not bound this kernel",
+                         "frac_at_timed_rate_is": "the same algorithmic bytes over ms_per_frame (the regime `value` is measured in): above 1 proves that algorithmic bytes / HBM peak does not bound this kernel",
                          "hbm_frac": hbm_frac, "valu": valu, "pmc": pmc,
                          "kernel": kernel, "kernel_ms": round(kernel_ms, 4),
                          **({"in_flight": in_flight_block} if in_flight_block else {}),
@@ -710,18 +716,18 @@ def main():
                          **({"gather": g_main} if g_main else {}),
                          "algorithmic_bytes_per_launch": int(alg_one),
                          "node_visits": int(sum(c.node_visits for c in cnts) / n_views), "tri_tests": int(sum(c.tri_tests for c in cnts) / n_views),
-                         "bytes_per_ray": round(alg_bytes / max(rays_step, 1), 1)},
+                         "bytes_per_ray": round(alg_bytes / max(rays_frame, 1), 1)},
         }
         if one_at_a_time:
             dt1, k1, rays1, alg1, _ = one_at_a_time
-            a1 = alg1 / args.steps / (k1 * 1e-3) / 1e9 if k1 > 0 else 0.0
-            out["one_frame_at_a_time"] = {"value": round(rays1 * (total_rays / max(rays_timed, 1)) / dt1 / 1e6, 2), "unit": "Mrays/s", "ms_per_step": round(dt1 / args.steps * 1e3, 4),
+            a1 = alg1 / n_frames_timed / (k1 * 1e-3) / 1e9 if k1 > 0 else 0.0
+            out["one_frame_at_a_time"] = {"value": round(rays1 * (total_rays / max(rays_timed, 1)) / dt1 / 1e6, 2), "unit": "Mrays/s", "ms_per_step": round(dt1 / args.steps * 1e3, 4), "ms_per_frame": round(dt1 / n_frames_timed * 1e3, 4),
                                           "steps": args.steps, "kernel_ms": round(k1, 4), "achieved": round(a1, 2), "frac": round(a1 / HBM_PEAK_GBS, 5),
                                           "note": "the same frames (same orbit) with --in-flight 1 (round 1's definition of value), measured after the timed region"}
         if same_view:
             dts, ks, rays_s, alg_s, _ = same_view
-            out["same_view"] = {"value": round(rays_s * (total_rays / max(rays_timed, 1)) / dts / 1e6, 2), "unit": "Mrays/s", "ms_per_step": round(dts / args.steps * 1e3, 4),
-                                "steps": args.steps, "frames_in_flight": n_in_flight, "rays_per_step_rank0": int(rays_v[0]),
+            out["same_view"] = {"value": round(rays_s * (total_rays / max(rays_timed, 1)) / dts / 1e6, 2), "unit": "Mrays/s", "ms_per_step": round(dts / args.steps * 1e3, 4), "ms_per_frame": round(dts / n_frames_timed * 1e3, 4),
+                                "steps": args.steps, "frames_in_flight": n_in_flight, "rays_per_frame_rank0": int(rays_v[0]),
                                 "note": "every frame the SAME camera (view 0), as rounds 1 and 2 timed it: frames in flight then share their working set in the caches"}
         if parity_multi:
             out["parity"] = parity_multi
@@ -736,7 +742,7 @@ def main():
             prim_g = prim_all.ravel()[pix]
             rgba_g = rgba_all.reshape(-1, 4)[pix]
             d = rgba_g.astype(np.float64) - rgba_o.astype(np.float64)
-            out["parity"] = {"frame": f"the last frame of the timed region (step {args.steps - 1}, view {last_view}, {n_in_flight} in flight, {kernel_timed})",
+            out["parity"] = {"frame": f"the last frame of the timed region (step {args.steps - 1}, frame {n_frames_timed - 1}, view {last_view}, {n_in_flight} in flight, {kernel_timed})",
                              "prim_id_agreement": float((prim_g == prim_o).mean()),
                              "radiance_rmse": float(np.sqrt(np.mean(d * d))), "pixels": int(len(pix))}
             # "additionally time the CPU BVH traversal on full frames" -- the oracle's scalar walk of the
@@ -793,9 +799,9 @@ def main():
             # (the same scene, 4 jittered samples per pixel) and configs[4]'s scene (10 M triangles, incoherent bounces) -- the
             # kernels furthest from any ceiling, with the counters of their committed passes quoted under
             # the same fingerprint guard.
-            steps_x = max(10, min(args.steps, 50))
+            steps_x = max(10, min(n_frames_timed, 50))
             try:
-                ns = side_workload(rt, orc, "soup_1m_1080p_primary_shadow", local_rank, args.steps, n_in_flight, check=False, rates=rates)
+                ns = side_workload(rt, orc, "soup_1m_1080p_primary_shadow", local_rank, max(10, min(n_frames_timed, 200)), n_in_flight, check=False, rates=rates)
                 ns["target"] = ">= 1000 Mrays/s primary+shadow at 1080p on a 1M-triangle scene (BASELINE.json north_star)"
                 out["north_star_scene"] = ns
             except Exception as ex:                                              # never fail the bench line for it

@@ -25,8 +25,8 @@ bash tools/pmc_full.sh r3_field "k_stream<false, true>" --in-flight 1 > $P/pmc_f
 RT_TUNE_STREAM_WAVES=8 bash tools/pmc_full.sh r3_field8 "k_stream8<false, true>" --in-flight 1 > $P/pmc_field8.log 2>&1 || { tail $P/pmc_field8.log; exit 1; }
 fi
 if [ "$STAGE" = "all" ] || [ "$STAGE" = "b" ]; then
-PMC_STEPS=3 bash tools/pmc_full.sh r3_path10m "k_path_start<false>;k_path_bounce<false>" --in-flight 1 --workload soup_10m_1080p_path_1spp_8seg > $P/pmc_path10m.log 2>&1 || { tail $P/pmc_path10m.log; exit 1; }
-PMC_STEPS=8 bash tools/pmc_full.sh r3_configs2 "k_path_start<false>" --in-flight 1 --workload soup_1m_1080p_4spp > $P/pmc_configs2.log 2>&1 || { tail $P/pmc_configs2.log; exit 1; }
+PMC_STEPS=1 bash tools/pmc_full.sh r3_path10m "k_path_start<false>;k_path_bounce<false>" --in-flight 1 --workload soup_10m_1080p_path_1spp_8seg > $P/pmc_path10m.log 2>&1 || { tail $P/pmc_path10m.log; exit 1; }
+PMC_STEPS=1 bash tools/pmc_full.sh r3_configs2 "k_path_start<false>" --in-flight 1 --workload soup_1m_1080p_4spp > $P/pmc_configs2.log 2>&1 || { tail $P/pmc_configs2.log; exit 1; }
 fi
 if [ "$STAGE" = "all" ] || [ "$STAGE" = "json" ]; then
 python profiles/pmc_to_json.py sphere_field_10k_1080p_primary_shadow 8 "profiles/r3/pmc_k_stream.txt, pmc_k_stream8.txt, pmc_path_1080p_soup_10m.txt, pmc_path_1080p_soup_1m_4spp.txt (rocprofv3 --pmc, one run per counter group, tools/profile_round3.sh)" \

@@ -191,6 +191,19 @@ __device__ __forceinline__ f3 exact_inv(f3 inv, f3 d) {
     }
     return inv;
 }
+// ---- wave priorities (round 3) ------------------------------------------------------------------------------------
+// A trip of the traversal loop is: vote -> addresses -> the node's (record's) loads -> wait -> ~125 (~60) VALU instructions of
+// slab tests, ordering and pushes -> next trip.  With eight waves on a SIMD the arbiter picks the oldest ready wave, so a wave
+// that is ten instructions away from issuing its next loads -- one or two microseconds of memory latency that nothing else can
+// start -- queues behind waves that have a hundred instructions of arithmetic ahead of them.  s_setprio (0..3, per wave, among
+// the waves of its SIMD) turns that into shortest-time-to-next-load-first: the priority RISES through the step and is dropped
+// as soon as the loads are out.  Same instructions, same results; measured (profiles/r3/ab_setprio*.txt): bench scene -5.6 %
+// one frame at a time, -6.4 % with four in flight; 1 M-triangle soup -4.5 % / -5 %; path tracing 10 M triangles +3 %, 4K +5 ... +7 %.
+#define RT_PRIO_ISSUE 3     // from the vote to the issue of the trip's loads; the hand-over (service) code, which ends in new rays
+#define RT_PRIO_WAIT 0      // loads issued: wait for them, start the step's arithmetic
+#define RT_PRIO_ORDER 1     // wide step: slab tests done, ordering the hit children
+#define RT_PRIO_PUSH 2      // wide step: children ordered, pushes and the next node left; record step: primitive test done
+#define RT_SETPRIO(p) __builtin_amdgcn_s_setprio(p)
 __device__ __forceinline__ float ub(uint32_t w, int k) { return (float)((w >> (8 * k)) & 0xFFu); }   // v_cvt_f32_ubyteK
 template <class Q>
 __device__ __forceinline__ void wide_decide(Q q0, Q q1, Q q2, Q q3, f3 o, f3 inv, float t, int &cur, int &sp, lds_int *stk,
@@ -225,9 +238,11 @@ __device__ __forceinline__ void wide_decide(Q q0, Q q1, Q q2, Q q3, f3 o, f3 inv
     // nearest child exactly, the rest roughly: three exchanges put the minimum first and leave (max01, second
     // minimum, max23) behind it; taking the second minimum next is right most of the time.  The full five-exchange
     // sort visits 1-3 % fewer nodes and is 0-2 % slower (10 VALU instructions more per step).
+    RT_SETPRIO(RT_PRIO_ORDER);
     RT_CE(0, 1) RT_CE(2, 3) RT_CE(0, 2)
     { const uint32_t tk = key[1]; const int tr = ref[1]; key[1] = key[2]; ref[1] = ref[2]; key[2] = tk; ref[2] = tr; }
 #undef RT_CE
+    RT_SETPRIO(RT_PRIO_PUSH);
     if (sp + 3 <= RT_STACK_LDS) {      // the usual case: three slots left in the LDS part
         if (ref[3] != RT_CHILD_NONE) { stk[sp * RT_BLOCK] = ref[3]; ++sp; }
         if (ref[2] != RT_CHILD_NONE) { stk[sp * RT_BLOCK] = ref[2]; ++sp; }
@@ -269,9 +284,10 @@ __device__ __forceinline__ void wide_decide(Q q0, Q q1, Q q2, Q q3, f3 o, f3 inv
 // wave instead of four vector loads per lane; only k_stream has the SGPRs to spare), the lane's ray (O, D, INV), its closest
 // hit so far (T, HU, HV, SEQ, REC), its place in the tree (CUR, SP, STK, OVF), ANY_ (any accepted hit ends the ray), the
 // wave's lane count N_ALL and ended-lane count N_DONE (read; the caller recounts after the trip), the vote weights, UNI_MIN,
-// the counters C and the lane id LANE.
+// the counters C and the lane id LANE.  The wave's priority follows the trip (RT_PRIO_*, above wide_decide).
 #define RT_VOTED_TRIP(NODES, RECS, MESHES, FLAGS, WIDE_, COUNT_, UNIFORM_, O, D, INV, T, HU, HV, SEQ, REC, CUR, SP, STK, OVF, ANY_, N_ALL, N_DONE, VOTE_NODE, VOTE_TRI, UNI_MIN, C, LANE) \
     { \
+        RT_SETPRIO(RT_PRIO_ISSUE); \
         const unsigned long long m_node_ = __ballot((CUR) >= 0); \
         const uint32_t n_node_ = (uint32_t)__builtin_popcountll(m_node_); \
         const uint32_t n_leaf_ = (N_ALL) - (N_DONE) - n_node_; \
@@ -287,6 +303,7 @@ __device__ __forceinline__ void wide_decide(Q q0, Q q1, Q q2, Q q3, f3 o, f3 inv
                 cfloat_ *sp_ = (cfloat_ *)(const void *)((NODES) + u0_); \
                 q4 q0 = {sp_[0], sp_[1], sp_[2], sp_[3]}, q1 = {sp_[4], sp_[5], sp_[6], sp_[7]}; \
                 q4 q2 = {sp_[8], sp_[9], sp_[10], sp_[11]}, q3 = {sp_[12], sp_[13], sp_[14], sp_[15]}; \
+                RT_SETPRIO(RT_PRIO_WAIT); \
                 if ((CUR) >= 0) { \
                     if (COUNT_) { (C).nodes++; if ((LANE) == (uint32_t)__builtin_ctzll(m_node_)) { (C).wnodes++; (C).walive += n_node_ + n_leaf_; } } \
                     if (WIDE_) wide_decide(q0, q1, q2, q3, (O), (INV), (T), (CUR), (SP), (STK), (OVF)); \
@@ -295,6 +312,7 @@ __device__ __forceinline__ void wide_decide(Q q0, Q q1, Q q2, Q q3, f3 o, f3 inv
             } else if ((CUR) >= 0) { \
                 const float4 *p_ = reinterpret_cast<const float4 *>((NODES) + (CUR)); \
                 float4 q0 = p_[0], q1 = p_[1], q2 = p_[2], q3 = p_[3]; \
+                RT_SETPRIO(RT_PRIO_WAIT); \
                 if (COUNT_) { (C).nodes++; if ((LANE) == (uint32_t)__builtin_ctzll(m_node_)) { (C).wnodes++; (C).walive += n_node_ + n_leaf_; } } \
                 if (WIDE_) wide_decide(q0, q1, q2, q3, (O), (INV), (T), (CUR), (SP), (STK), (OVF)); \
                 else node_decide(q0, q1, q2, q3, (O), (INV), (T), (CUR), (SP), (STK), (OVF)); \
@@ -307,9 +325,11 @@ __device__ __forceinline__ void wide_decide(Q q0, Q q1, Q q2, Q q3, f3 o, f3 inv
                     const uint32_t first_ = code_ >> 3, left_ = code_ & 7u; \
                     const float4 *r_ = reinterpret_cast<const float4 *>((RECS) + first_); \
                     float4 r0 = r_[0], r1 = r_[1], r2 = r_[2]; \
+                    RT_SETPRIO(RT_PRIO_WAIT); \
                     if (COUNT_) { (C).tris++; if ((LANE) == (uint32_t)__builtin_ctzll(__ballot(true))) (C).wtris++; } \
                     float dst_, u_, v_; \
                     bool ok_ = prim_test((O), (D), r0, r1, r2, dst_, u_, v_); \
+                    RT_SETPRIO(RT_PRIO_PUSH); \
                     const uint32_t sq_ = __float_as_uint(r2.w); \
                     ok_ = ok_ && (dst_ < (T) || (dst_ == (T) && sq_ < (SEQ))); \
                     if (ok_ && !((FLAGS) & RT_FLAG_NO_MESH_CULL) && __float_as_uint(r2.z) != RT_REC_SPHERE) {   /* per-mesh AABB cull of wgsl:155 */ \
@@ -759,6 +779,7 @@ __device__ __forceinline__ void stream_body(
         // this barrier the compiler loads all of it once at kernel start, into ~40 VGPRs that it then has to spill
         // (every lane of every wave storing 176 B at start-up: 80 MB of a frame's 203 MB of writes in round 1).
         __asm__ volatile("" ::: "memory");
+        RT_SETPRIO(RT_PRIO_ISSUE);
         // ---- 1. finish ended rays (shade, write, start the shadow ray) -----------------------------------------
         if (cur == RT_DONE && state == 1) {
             float4 out = make_float4(0.0f, 0.0f, 0.0f, 0.0f);      // miss: vec4(0) (wgsl:210)

@@ -306,7 +306,8 @@ void rt_host_bvh_free(rt_host_bvh *bvh);
  * bench.py's roofline.gather uses instead of the HBM streaming peak.  Fills ggather_per_s[0..9] with 10^9 gathers of 64 B per
  * second, as pairs {independent (throughput), dependent (pointer chase)} for buffers of 16 KiB (vector L1), 2 MiB (L2 of every
  * XCD), 128 MiB (Infinity Cache), 1 GiB and 4 GiB (HBM).  Allocates 4 GiB of device memory for the call (RT_ERR_OOM if it
- * cannot) and takes about a second; runs in the caller's process on a stream of its own. */
+ * cannot) and takes about a second; runs in the caller's process on a stream of its own and leaves the thread's current
+ * device as it found it. */
 #define RT_GATHER_RATE_VALUES 10
 int rt_measure_gather_rates(int device_ordinal, double *ggather_per_s, size_t n_values);
 

@@ -51,7 +51,12 @@ extern "C" int rt_measure_gather_rates(int device_ordinal, double *ggather_per_s
     if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0) return RT_ERR_NO_GPU;
     if (device_ordinal < 0 || device_ordinal >= n_dev) return RT_ERR_ARG;
     hipDeviceProp_t prop;
-    if (hipSetDevice(device_ordinal) != hipSuccess || hipGetDeviceProperties(&prop, device_ordinal) != hipSuccess) return RT_ERR_HIP;
+    int prev_dev = -1;
+    (void)hipGetDevice(&prev_dev);                 // the caller's current device is put back before returning
+    if (hipSetDevice(device_ordinal) != hipSuccess || hipGetDeviceProperties(&prop, device_ordinal) != hipSuccess) {
+        if (prev_dev >= 0) (void)hipSetDevice(prev_dev);
+        return RT_ERR_HIP;
+    }
     const size_t sizes[RT_GATHER_RATE_VALUES / 2] = {(size_t)16 << 10, (size_t)2 << 20, (size_t)128 << 20, (size_t)1 << 30, (size_t)4 << 30};
     const size_t max_bytes = sizes[RT_GATHER_RATE_VALUES / 2 - 1];
     uint4 *buf = nullptr; unsigned *out = nullptr;
@@ -73,7 +78,7 @@ extern "C" int rt_measure_gather_rates(int device_ordinal, double *ggather_per_s
                     if (dep) hipLaunchKernelGGL(k_tool_gather<true>, dim3(grid), dim3(256), 0, st, buf, mask, iters, out);
                     else hipLaunchKernelGGL(k_tool_gather<false>, dim3(grid), dim3(256), 0, st, buf, mask, iters, out);
                     (void)hipEventRecord(e1, st);
-                    if (hipEventSynchronize(e1) != hipSuccess) { rc = RT_ERR_HIP; break; }
+                    if (hipGetLastError() != hipSuccess || hipEventSynchronize(e1) != hipSuccess) { rc = RT_ERR_HIP; break; }
                 }
                 float ms = 0.0f;
                 if (rc != RT_OK || hipEventElapsedTime(&ms, e0, e1) != hipSuccess || !(ms > 0.0f)) { rc = RT_ERR_HIP; break; }
@@ -86,5 +91,6 @@ extern "C" int rt_measure_gather_rates(int device_ordinal, double *ggather_per_s
     if (st) (void)hipStreamDestroy(st);
     if (out) (void)hipFree(out);
     if (buf) (void)hipFree(buf);
+    if (prev_dev >= 0 && prev_dev != device_ordinal) (void)hipSetDevice(prev_dev);
     return rc;
 }

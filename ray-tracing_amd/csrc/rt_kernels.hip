@@ -1485,12 +1485,17 @@ hipError_t rtk_launch_primary(hipStream_t st, const RtSceneDev &S, const RtViewD
         // With 3-4 frames in flight a CU holds blocks of several launches; 5 per launch instead of 8 leave room for the next
         // frames' blocks and each launch a shorter tail (tools/ab_in_flight_knobs.py, 4 in flight: bench scene 0.603 -> 0.597 ms,
         // 1 M-triangle soup 0.412 -> 0.396; one frame at a time the same setting costs 10 %)
-        if (per_cu == 0) per_cu = tree <= ((size_t)4 << 20) ? 3u : (tree <= ((size_t)16 << 20) || tune.frames_in_flight >= 3u ? 5u : 8u);
+        // A SHARD of a frame (tiles mode at N >= 4: at most 8 blocks per CU of work in the whole launch) with frames in flight: 3 per
+        // launch, so that the launches in flight are resident together and a wave takes more than one region
+        // (profiles/r3/shard_time_blocks.txt, one GPU playing one rank of N = 4 / 8, 4 in flight: 0.156 -> 0.151 / 0.096 -> 0.092 ms)
+        const uint32_t need_blocks = (sh.n_owned * sh.tile * sh.tile + RT_BLOCK - 1) / RT_BLOCK;
+        const uint32_t in_flight_per_cu = need_blocks <= 8u * tune.cus ? 3u : 5u;
+        if (per_cu == 0) per_cu = tree <= ((size_t)4 << 20) ? 3u : (tune.frames_in_flight >= 3u ? in_flight_per_cu : (tree <= ((size_t)16 << 20) ? 5u : 8u));
         // 8 waves per SIMD with frames in flight (k_stream8), else the 7-wave build; tune.stream_waves (7 / 8) overrides for A/Bs
         const bool eight = tune.stream_waves ? tune.stream_waves == 8u : tune.frames_in_flight >= 3u;
         const uint32_t cu_holds = eight ? 8u : (uint32_t)RT_STREAM_WAVES;
         if (per_cu > cu_holds) per_cu = cu_holds;      // what a CU can hold: later blocks would only find empty queues
-        uint32_t need = (sh.n_owned * sh.tile * sh.tile + RT_BLOCK - 1) / RT_BLOCK;
+        const uint32_t need = need_blocks;
         uint32_t grid = tune.cus * per_cu < need ? tune.cus * per_cu : need;
         if (grid == 0) return hipSuccess;
         const bool wide = S.n_wide != 0u && !(flags & RT_FLAG_BINARY_TREE);

@@ -130,6 +130,19 @@ __device__ __forceinline__ int stack_pop(int &sp, const lds_int *stk, const prv_
     if (sp >= RT_STACK_LDS) v = ovf[sp - RT_STACK_LDS];
     return v;
 }
+// Pop with the LDS part's top entry already in a register (read at the start of the trip, when the trip's loads were issued:
+// a step pops only if it pushed nothing, so the entry is still the top): the LDS round trip leaves the trip's critical path.
+__device__ __forceinline__ int stack_pop_pref(int &sp, const prv_int *ovf, int tos_pref) {
+    if (sp == 0) return RT_DONE;
+    --sp;
+    int v = tos_pref;
+    if (sp >= RT_STACK_LDS) v = ovf[sp - RT_STACK_LDS];
+    return v;
+}
+__device__ __forceinline__ int stack_peek_lds(int sp, const lds_int *stk) {
+    const int i = sp > 0 ? sp - 1 : 0;
+    return stk[(i < RT_STACK_LDS ? i : RT_STACK_LDS - 1) * RT_BLOCK];
+}
 __device__ __forceinline__ void stack_push(int &sp, lds_int *stk, prv_int *ovf, int v) {
     if (sp < RT_STACK_LDS) stk[sp * RT_BLOCK] = v;
     else if (sp - RT_STACK_LDS < RT_STACK_OVF) ovf[sp - RT_STACK_LDS] = v;
@@ -139,9 +152,9 @@ __device__ __forceinline__ void stack_push(int &sp, lds_int *stk, prv_int *ovf, 
 
 // One node step: the two child boxes of the fetched node against the lane's ray, then descend / push / pop.
 // Q: float4 (per-lane vector fetch) or q4 (one scalar fetch for the whole wave, operands in SGPRs).
-template <class Q>
+template <bool PREF, class Q>
 __device__ __forceinline__ void node_decide(Q q0, Q q1, Q q2, Q q3, f3 o, f3 inv, float t, int &cur, int &sp, lds_int *stk,
-                                            prv_int *ovf) {
+                                            prv_int *ovf, int tos_pref) {
     const float limit = t * 1.00001f;   // relaxed bound: near-ties are still visited, seq decides
     float ax0 = (q0.x - o.x) * inv.x, ax1 = (q0.w - o.x) * inv.x;
     float ay0 = (q0.y - o.y) * inv.y, ay1 = (q1.x - o.y) * inv.y;
@@ -161,7 +174,7 @@ __device__ __forceinline__ void node_decide(Q q0, Q q1, Q q2, Q q3, f3 o, f3 inv
     bool swap = tmin1 < tmin0;
     if (both) stack_push(sp, stk, ovf, swap ? c0 : c1);
     if (h0 || h1) cur = (both ? swap : h1) ? c1 : c0;
-    else cur = stack_pop(sp, stk, ovf);
+    else cur = PREF ? stack_pop_pref(sp, ovf, tos_pref) : stack_pop(sp, stk, ovf);
 }
 
 // One step on the 4-wide tree: four quantised child boxes against the lane's ray, the hit ones sorted by entry
@@ -205,9 +218,9 @@ __device__ __forceinline__ f3 exact_inv(f3 inv, f3 d) {
 #define RT_PRIO_PUSH 2      // wide step: children ordered, pushes and the next node left; record step: primitive test done
 #define RT_SETPRIO(p) __builtin_amdgcn_s_setprio(p)
 __device__ __forceinline__ float ub(uint32_t w, int k) { return (float)((w >> (8 * k)) & 0xFFu); }   // v_cvt_f32_ubyteK
-template <class Q>
+template <bool PREF, class Q>
 __device__ __forceinline__ void wide_decide(Q q0, Q q1, Q q2, Q q3, f3 o, f3 inv, float t, int &cur, int &sp, lds_int *stk,
-                                            prv_int *ovf) {
+                                            prv_int *ovf, int tos_pref) {
     const float limit = t * 1.00001f;   // relaxed bound: near-ties are still visited, seq decides
     // plane = org + byte*scl  =>  distance = byte*A - B with A = scl*inv, B = (o - org)*inv: one fma per plane.
     // (Two children per v_pk_fma_f32 was measured: 1 % slower -- packed f32 issues at half rate here.)
@@ -269,7 +282,7 @@ __device__ __forceinline__ void wide_decide(Q q0, Q q1, Q q2, Q q3, f3 o, f3 inv
     }
 #endif
     if (ref[0] != RT_CHILD_NONE) cur = ref[0];
-    else cur = stack_pop(sp, stk, ovf);
+    else cur = PREF ? stack_pop_pref(sp, ovf, tos_pref) : stack_pop(sp, stk, ovf);
 }
 
 // ---- the voted trip: ONE source for the loop body of every per-lane traversal (traverse<> and stream_body; round 3) --------
@@ -285,7 +298,7 @@ __device__ __forceinline__ void wide_decide(Q q0, Q q1, Q q2, Q q3, f3 o, f3 inv
 // hit so far (T, HU, HV, SEQ, REC), its place in the tree (CUR, SP, STK, OVF), ANY_ (any accepted hit ends the ray), the
 // wave's lane count N_ALL and ended-lane count N_DONE (read; the caller recounts after the trip), the vote weights, UNI_MIN,
 // the counters C and the lane id LANE.  The wave's priority follows the trip (RT_PRIO_*, above wide_decide).
-#define RT_VOTED_TRIP(NODES, RECS, MESHES, FLAGS, WIDE_, COUNT_, UNIFORM_, O, D, INV, T, HU, HV, SEQ, REC, CUR, SP, STK, OVF, ANY_, N_ALL, N_DONE, VOTE_NODE, VOTE_TRI, UNI_MIN, C, LANE) \
+#define RT_VOTED_TRIP(NODES, RECS, MESHES, FLAGS, WIDE_, COUNT_, UNIFORM_, PREF_, O, D, INV, T, HU, HV, SEQ, REC, CUR, SP, STK, OVF, ANY_, N_ALL, N_DONE, VOTE_NODE, VOTE_TRI, UNI_MIN, C, LANE) \
     { \
         RT_SETPRIO(RT_PRIO_ISSUE); \
         const unsigned long long m_node_ = __ballot((CUR) >= 0); \
@@ -303,19 +316,21 @@ __device__ __forceinline__ void wide_decide(Q q0, Q q1, Q q2, Q q3, f3 o, f3 inv
                 cfloat_ *sp_ = (cfloat_ *)(const void *)((NODES) + u0_); \
                 q4 q0 = {sp_[0], sp_[1], sp_[2], sp_[3]}, q1 = {sp_[4], sp_[5], sp_[6], sp_[7]}; \
                 q4 q2 = {sp_[8], sp_[9], sp_[10], sp_[11]}, q3 = {sp_[12], sp_[13], sp_[14], sp_[15]}; \
+                const int tp_ = (PREF_) ? stack_peek_lds((SP), (STK)) : 0; \
                 RT_SETPRIO(RT_PRIO_WAIT); \
                 if ((CUR) >= 0) { \
                     if (COUNT_) { (C).nodes++; if ((LANE) == (uint32_t)__builtin_ctzll(m_node_)) { (C).wnodes++; (C).walive += n_node_ + n_leaf_; } } \
-                    if (WIDE_) wide_decide(q0, q1, q2, q3, (O), (INV), (T), (CUR), (SP), (STK), (OVF)); \
-                    else node_decide(q0, q1, q2, q3, (O), (INV), (T), (CUR), (SP), (STK), (OVF)); \
+                    if (WIDE_) wide_decide<PREF_>(q0, q1, q2, q3, (O), (INV), (T), (CUR), (SP), (STK), (OVF), tp_); \
+                    else node_decide<PREF_>(q0, q1, q2, q3, (O), (INV), (T), (CUR), (SP), (STK), (OVF), tp_); \
                 } \
             } else if ((CUR) >= 0) { \
                 const float4 *p_ = reinterpret_cast<const float4 *>((NODES) + (CUR)); \
                 float4 q0 = p_[0], q1 = p_[1], q2 = p_[2], q3 = p_[3]; \
+                const int tp_ = (PREF_) ? stack_peek_lds((SP), (STK)) : 0; \
                 RT_SETPRIO(RT_PRIO_WAIT); \
                 if (COUNT_) { (C).nodes++; if ((LANE) == (uint32_t)__builtin_ctzll(m_node_)) { (C).wnodes++; (C).walive += n_node_ + n_leaf_; } } \
-                if (WIDE_) wide_decide(q0, q1, q2, q3, (O), (INV), (T), (CUR), (SP), (STK), (OVF)); \
-                else node_decide(q0, q1, q2, q3, (O), (INV), (T), (CUR), (SP), (STK), (OVF)); \
+                if (WIDE_) wide_decide<PREF_>(q0, q1, q2, q3, (O), (INV), (T), (CUR), (SP), (STK), (OVF), tp_); \
+                else node_decide<PREF_>(q0, q1, q2, q3, (O), (INV), (T), (CUR), (SP), (STK), (OVF), tp_); \
             } \
         } else { \
             if ((CUR) < 0 && (CUR) != RT_DONE) { \
@@ -325,6 +340,7 @@ __device__ __forceinline__ void wide_decide(Q q0, Q q1, Q q2, Q q3, f3 o, f3 inv
                     const uint32_t first_ = code_ >> 3, left_ = code_ & 7u; \
                     const float4 *r_ = reinterpret_cast<const float4 *>((RECS) + first_); \
                     float4 r0 = r_[0], r1 = r_[1], r2 = r_[2]; \
+                    const int tp_ = (PREF_) ? stack_peek_lds((SP), (STK)) : 0; \
                     RT_SETPRIO(RT_PRIO_WAIT); \
                     if (COUNT_) { (C).tris++; if ((LANE) == (uint32_t)__builtin_ctzll(__ballot(true))) (C).wtris++; } \
                     float dst_, u_, v_; \
@@ -340,7 +356,7 @@ __device__ __forceinline__ void wide_decide(Q q0, Q q1, Q q2, Q q3, f3 o, f3 inv
                     } \
                     if (ok_) { (T) = dst_; (SEQ) = sq_; (REC) = first_; (HU) = u_; (HV) = v_; }   /* tri / mesh: read back from the record when the ray ends */ \
                     if (ok_ && (ANY_)) (CUR) = RT_DONE;                       /* shadow ray: any hit answers it */ \
-                    else if (left_ == 0u) (CUR) = stack_pop((SP), (STK), (OVF)); \
+                    else if (left_ == 0u) (CUR) = (PREF_) ? stack_pop_pref((SP), (OVF), tp_) : stack_pop((SP), (STK), (OVF)); \
                     else (CUR) = ~(int)(((first_ + 1u) << 3) | (left_ - 1u)); \
                 } \
             } \
@@ -363,7 +379,7 @@ __device__ __forceinline__ void wide_decide(Q q0, Q q1, Q q2, Q q3, f3 o, f3 inv
 // triangle step as soon as a quarter of the unfinished rays wait at a leaf -- early hits shorten
 // everything that follows.)
 // All lanes that call this must call it together (it counts them with a ballot).
-template <bool ANY, bool COUNT, bool WIDE>
+template <bool ANY, bool COUNT, bool WIDE, bool PREF = false>
 __device__ __forceinline__ void traverse(const RtSceneDev &S, f3 o, f3 d, uint32_t flags, int *stk_generic, Hit &h, Cnt &c,
                                          uint32_t vote_node = 3u, uint32_t vote_tri = 1u) {
     h.hit = false; h.t = RT_INF; h.u = 0.0f; h.v = 0.0f; h.seq = 0xFFFFFFFFu; h.tri = 0xFFFFFFFFu; h.mesh = 0;
@@ -381,7 +397,7 @@ __device__ __forceinline__ void traverse(const RtSceneDev &S, f3 o, f3 d, uint32
     uint32_t rec = 0xFFFFFFFFu;           // the accepted record: one register instead of hit flag + tri + mesh
     const uint32_t lane = threadIdx.x & 63u;
     do {
-        RT_VOTED_TRIP(nodes, S.recs, S.meshes, flags, WIDE, COUNT, false, o, d, inv, h.t, h.u, h.v, h.seq, rec, cur, sp, stk, ovf, ANY,
+        RT_VOTED_TRIP(nodes, S.recs, S.meshes, flags, WIDE, COUNT, false, PREF, o, d, inv, h.t, h.u, h.v, h.seq, rec, cur, sp, stk, ovf, ANY,
                       n_all, n_done, vote_node, vote_tri, 65u, c, lane)
         n_done = (uint32_t)__builtin_popcountll(__ballot(cur == RT_DONE));
     } while (n_done != n_all);
@@ -541,11 +557,15 @@ __device__ __forceinline__ void brute_force(const RtSceneDev &S, f3 o, f3 d, uin
     }
 }
 
-template <bool ANY, bool COUNT>
+// PREF: pops take the LDS stack's top entry from a register filled at the start of the trip (stack_pop_pref).  On for the
+// bounce segments of the path tracer, whose incoherent rays wait for memory with few lanes alive (10 M triangles: + 3.6 %); off for
+// coherent rays, where the extra LDS read per trip costs more than the shorter pop saves (k_stream + 0.5 ... + 1.5 %;
+// profiles/r3/ab_tos_prefetch.txt).
+template <bool ANY, bool COUNT, bool PREF = false>
 __device__ __forceinline__ void trace(const RtSceneDev &S, f3 o, f3 d, uint32_t flags, int *stk, Hit &h, Cnt &c) {
     if (flags & RT_FLAG_BRUTE_FORCE) brute_force<ANY, COUNT>(S, o, d, flags, h, c);
-    else if (S.n_wide != 0u && !(flags & RT_FLAG_BINARY_TREE)) traverse<ANY, COUNT, true>(S, o, d, flags, stk, h, c);   // kernel-uniform choice
-    else traverse<ANY, COUNT, false>(S, o, d, flags, stk, h, c);
+    else if (S.n_wide != 0u && !(flags & RT_FLAG_BINARY_TREE)) traverse<ANY, COUNT, true, PREF>(S, o, d, flags, stk, h, c);   // kernel-uniform choice
+    else traverse<ANY, COUNT, false, PREF>(S, o, d, flags, stk, h, c);
 }
 
 // point and interpolated vertex normal of an accepted hit: ray_tracing.wgsl:137-138
@@ -871,7 +891,7 @@ __device__ __forceinline__ void stream_body(
         const uint32_t n_idle = (uint32_t)__builtin_popcountll(__ballot(state == 0));
         uint32_t n_done = (uint32_t)__builtin_popcountll(__ballot(cur == RT_DONE)), n_pend, n_live;
         do {
-            RT_VOTED_TRIP(nodes, recs, meshes, flags, WIDE, COUNT, true, o, d, inv, t, hu, hv, seq, rec, cur, sp, stk, ovf, any,
+            RT_VOTED_TRIP(nodes, recs, meshes, flags, WIDE, COUNT, true, false, o, d, inv, t, hu, hv, seq, rec, cur, sp, stk, ovf, any,
                           64u, n_done, vote_node, vote_tri, uni_min, c, lane)
             n_done = (uint32_t)__builtin_popcountll(__ballot(cur == RT_DONE));
             n_pend = n_done - n_idle;
@@ -1115,6 +1135,9 @@ __global__ __launch_bounds__(RT_BLOCK, RT_MIN_WAVES) void k_path_start(RtSceneDe
 // wide tree (refill thresholds 16-64, 256-path chunks per wave): lanes that start together fetch the same
 // top-of-tree nodes in the same instruction, which the L1 front end serves as one line; desynchronised lanes
 // do not.  DESIGN.md section 4.)
+#ifndef RT_BOUNCE_PREF
+#define RT_BOUNCE_PREF true
+#endif
 template <bool COUNT>
 __global__ __launch_bounds__(RT_BLOCK, RT_MIN_WAVES) void k_path_bounce(RtSceneDev S, uint32_t flags, int is_last,
                                                           float4 *__restrict__ contrib, uint32_t n_px, RtPathQueue qi, RtPathQueue qo,
@@ -1135,7 +1158,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_MIN_WAVES) void k_path_bounce(RtSceneD
             o = F3(qi.ox[i], qi.oy[i], qi.oz[i]);
             d = F3(qi.dx[i], qi.dy[i], qi.dz[i]);
             Hit h;
-            trace<false, COUNT>(S, o, d, flags, stk, h, c);
+            trace<false, COUNT, RT_BOUNCE_PREF>(S, o, d, flags, stk, h, c);
             col = F3(qi.cr[i], qi.cg[i], qi.cb[i]);              // fetched after the traversal (registers)
             rng = qi.rng[i]; pixel = qi.pixel[i];                // pixel | sample slot << RT_PATH_SLOT_SHIFT
             alive = path_scatter(S, h, o, d, col, rng, contrib + (size_t)(pixel >> RT_PATH_SLOT_SHIFT) * n_px + (pixel & RT_PATH_PIXEL_MASK)) && !is_last;

@@ -159,3 +159,49 @@ def test_measure_gather_rates_orders_the_memory_hierarchy():
     assert rt.lib().rt_measure_gather_rates(0, vals, 9) == rt.RT_ERR_ARG
     assert rt.lib().rt_measure_gather_rates(99, vals, 10) == rt.RT_ERR_ARG
     assert rt.lib().rt_measure_gather_rates(0, None, 10) == rt.RT_ERR_ARG
+
+
+@pytest.mark.parametrize("extra", [0, rt.FLAG_BINARY_TREE])
+def test_bounce_rays_pop_through_the_private_part_of_the_stack(extra):
+    """The bounce kernel pops from a register filled at the start of the trip (stack_pop_pref), the LDS part of the stack only;
+    entries beyond 16 live in the private array.  250 k parallel triangles stacked along -z behind a floor: a bounce ray that
+    leaves the floor towards the stack descends to the front triangle with a far child pushed on every level, then pops its
+    way back through both parts of the stack.  The running sums must be those of the oracle's walk of the device's own tree
+    (unbounded stack, scalar), and of the reference-shaped loop on a crop of the frame."""
+    n, W, H = 250_000, 40, 24
+    z = -(np.arange(n, dtype=np.float32) * np.float32(0.01))
+    verts = np.zeros(3 * n + 3, rt.VERTEX)
+    base = np.array([(-4.0, -3.0), (4.0, -3.0), (0.0, 5.0)], np.float32)
+    verts["pos"][:3 * n, :2] = np.tile(base, (n, 1))
+    verts["pos"][:3 * n, 2] = np.repeat(z, 3)
+    verts["norm"][:3 * n] = (0.0, 0.0, 1.0)
+    # the floor: one triangle in front of the stack, a little above the stack's lower edge, facing up
+    verts["pos"][3 * n:] = [(-6.0, -2.5, 0.5), (0.0, -2.5, 9.0), (6.0, -2.5, 0.5)]
+    verts["norm"][3 * n:] = (0.0, 1.0, 0.0)
+    tris = np.zeros(n + 1, rt.TRIANGLE); tris["indices"] = np.arange(3 * (n + 1), dtype=np.uint32).reshape(n + 1, 3)
+    meshes = np.zeros(2, rt.MESH_INFO)
+    meshes["first_tri"], meshes["tri_count"], meshes["material"] = (0, n), (n, 1), (0, 1)
+    meshes["aabb_min"][:] = [(-5, -4, float(z[-1]) - 1), (-7, -3, 0)]
+    meshes["aabb_max"][:] = [(5, 6, 1), (7, -2, 10)]
+    mats = np.zeros(2, rt.MATERIAL); mats["color"][:] = [(0.9, 0.5, 0.1, 1.0), (0.8, 0.8, 0.8, 1.0)]
+    scene = rt.Scene(tris, meshes, verts, mats)
+    app = rt.App()
+    app.camera_look_at((0.0, 4.0, 9.0), (0.0, -2.5, 3.0), (0, 1, 0))           # looks down at the floor
+    app.camera_set_target(W, H)
+    m, p = app.camera_view()
+    osc, view = oracle_scene(scene), orc.make_view(m, p, W, H)
+    with rt.Context(0) as ctx:
+        ctx.upload_scene(scene)
+        info = ctx.bvh_info()
+        assert info.max_depth > 16 and info.wide_stack_need > 16
+        ctx.set_view(m, p, W, H)
+        tree = orc.Tree(*ctx.read_bvh(), None if extra else ctx.read_bvh_wide())
+        assert ctx.render(flags=rt.FLAG_PATH_TRACE | rt.FLAG_COUNTERS | extra, spp=4, max_segments=4, seed=5, stream_id=1) == rt.RT_OK
+        acc_g, c = ctx.read_accumulation(), ctx.counters()
+        acc_w, segs_w, (nv, tt, mc) = orc.render_path_tree(osc, tree, view, spp=4, max_segments=4, seed=5, stream=1, threads=16)
+        assert c.rays_bounce > W * H                                           # the floor was hit and scattered
+        assert bitwise_equal(acc_g, acc_w) and c.rays_primary + c.rays_bounce == segs_w
+        assert (c.node_visits, c.tri_tests) == (nv, tt)
+        # a bounce ray that leaves the floor towards the stack does find its front triangle (the oracle's walk, one ray)
+        h, _ = orc.hit_tree(osc, tree, (0.0, -2.499, 3.0), (0.0, 0.05, -1.0))
+        assert h["hit"] and h["prim"] == 0
